@@ -1,0 +1,159 @@
+/*
+ * dadd_hip.h — C ABI of libdadd_hip.so: the MI355X (gfx950) kernels behind the DADD /
+ * IP-Adapter DDIM sampler.
+ *
+ * The reference (umutdundar99/progressive-stable-diffusion) is pure Python with no FFI; its
+ * hot path runs through PyTorch / diffusers operators.  Each entry point below replaces the
+ * operator sequence cited next to it (paths relative to the reference repo).  A reference-side
+ * binding would be a ctypes stub per function.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host
+ *   - activations: fp16, NHWC (== token-major [B, H*W, C]); latents / eps / frames: fp32 NCHW
+ *   - weights: fp16, [Cout][ky][kx][Cin] (K contiguous); biases and norm affine: fp32
+ *   - `stream` is a hipStream_t passed as void*; no entry point allocates, frees or
+ *     synchronises, so all of them may be captured into a hipGraph
+ *   - the library borrows memory, it never owns or frees caller buffers
+ *   - return value: DADD_OK or a negative DADD_E* code; dadd_last_error() gives the text
+ */
+#ifndef DADD_HIP_H
+#define DADD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DADD_OK 0
+#define DADD_EINVAL (-1) /* shape / alignment contract violated (Python raises ValueError) */
+#define DADD_EHIP (-2)   /* a HIP runtime call failed (Python raises RuntimeError) */
+#define DADD_ESTATE (-3) /* capture / profiling state misuse */
+
+/* epilogue flags of dadd_conv_igemm_f16 */
+#define DADD_EPI_BIAS 1     /* + bias[n] */
+#define DADD_EPI_ROWVEC 2   /* + rowvec[b][n]   (time-embedding projection of the sample) */
+#define DADD_EPI_RESIDUAL 4 /* + residual[m][n] */
+#define DADD_EPI_GEGLU 8    /* out[m][n/2] = hidden * gelu(gate); weight rows pre-interleaved */
+
+/* cross-attention modes of dadd_tri_xattn_f16 */
+#define DADD_XATTN_SPLIT 0    /* triple pathway, independent softmaxes */
+#define DADD_XATTN_BASELINE 1 /* one joint softmax over [AOE|image] */
+
+const char* dadd_last_error(void);
+int dadd_version(void);
+/* one-time per-process setup on the current device (kernel attributes); call before any launch
+ * and outside stream capture */
+int dadd_init(void);
+/* out[0]=CU count, out[1]=LDS bytes/CU, out[2]=clock kHz, out[3]=gcnArch as int (950) */
+int dadd_device_info(int device, int64_t out[4]);
+
+/* ---- implicit-GEMM convolution / linear on MFMA -------------------------------------------
+ * out[m][n] = epi( sum_{tap,c} x[b, oy*stride+ky-pad, ox*stride+kx-pad, c] * w[n][tap][c] )
+ * m = (b*Ho+oy)*Wo+ox.  taps = 1 (linear / conv1x1) or 9 (conv3x3).  `ups` = 1 reads x through
+ * a nearest 2x upsample (the virtual input is 2Hi x 2Wi).  Channels [0,C1) come from x,
+ * [C1,C1+C2) from x2 (skip-concat without materialising torch.cat).
+ * Replaces: F.conv2d / nn.Linear inside diffusers ResnetBlock2D, Transformer2DModel,
+ * Downsample2D, Upsample2D, FeedForward(GEGLU) and the to_q/to_k/to_v/to_out Linears that the
+ * reference calls at src/models/unet/unet.py:140-144, src/models/vae/vae.py:88,112 and
+ * src/models/attention_processor_routing_gates.py:123,133-137,161-162,183.
+ * Contract: (C1+C2) % 64 == 0, C1 % 64 == 0, N % 8 == 0, 16-byte aligned pointers.
+ * splitk > 1 needs `partial` (fp32, splitk*M*N) and is finished by the same call. */
+typedef struct {
+  const void* x;
+  const void* x2;
+  const void* w;
+  void* out;
+  float* partial;
+  const float* bias;
+  const float* rowvec;
+  const void* residual;
+  int32_t B, Hi, Wi, C1, C2, Ho, Wo, N;
+  int32_t taps, stride, ups, pad;
+  int32_t ldo, ldr, ld_rowvec;
+  int32_t splitk, flags, tile_n; /* tile_n: 128 or 160 (0 = choose) */
+} dadd_igemm_desc;
+int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
+
+/* ---- the two thin-channel convolutions at the UNet / VAE ends ------------------------------
+ * conv_in : x fp16 NHWC with 8 stored channels (4 or 3 real) -> fp16 NHWC Cout.
+ * conv_out: fp16 NHWC C -> fp32 NCHW Cout<=4; mode 1 also applies clamp(-1,1),(x+1)/2,clamp(0,1)
+ * (= _latents_to_images tail, src/pipelines/inference/inference_pipeline_ip.py:484-486). */
+int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* bias, void* out, int B, int H,
+                          int W, int Cout, void* stream);
+int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw, int B,
+                           int H, int W, int C, int Cout, int mode, void* stream);
+
+/* fp32 NCHW (C real channels, C<=8) -> fp16 NHWC with 8 channels (zero padded), times `scale`;
+ * optional CxC matrix + bias applied per pixel first (AutoencoderKL.post_quant_conv 1x1).
+ * Replaces latents / latent_scale (inference_pipeline_ip.py:476) + layout change. */
+int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B, int C, int H, int W,
+                                    float scale, const float* mat, const float* vec, void* stream);
+
+/* ---- normalisation -------------------------------------------------------------------------
+ * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
+ * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats.
+ * Replaces nn.GroupNorm(+F.silu) in ResnetBlock2D / Transformer2DModel / VAE (+ torch.cat). */
+#define DADD_GN_MAX_CHUNKS 64
+int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
+                       const float* beta, void* out, float* ws, int B, int HW, int groups,
+                       float eps, int silu, void* stream);
+/* LayerNorm over the last dim of [M][C] fp16 (BasicTransformerBlock.norm1/2/3). */
+int dadd_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int M,
+                       int C, float eps, void* stream);
+
+/* ---- attention -----------------------------------------------------------------------------
+ * Flash self-attention, softmax(QK^T/sqrt(d))V, never materialising the scores.
+ * q/k/v rows: token (b,n) at ptr + (b*N+n)*ld + head*d.  d in {40,80,160,512}.
+ * Replaces diffusers AttnProcessor2_0 / F.scaled_dot_product_attention on attn1
+ * (src/models/attention_processor_routing_gates.py:286) and the VAE mid-block attention. */
+int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int N,
+                       int heads, int d, int ld_qkv, int ld_out, void* stream);
+
+/* Fused DADD cross-attention.  q: [B][N][C]; kv: [B][T][ld_kv] holds the step-invariant
+ * projections of the conditioning tokens: columns [0,C)=to_k, [C,2C)=to_v, [2C,3C)=to_k_dis,
+ * [3C,4C)=to_v_dis (baseline: only the first 2C, T=32).
+ * SPLIT (T=48): z = anat_gate*softmax(q K_anat^T/sqrt d) V_anat          tokens [16,32), to_k/to_v
+ *                 + dis_gate *softmax(q K_dis^T /sqrt d) V_dis           tokens [0,16),  to_*_dis
+ *                 + lambda   *softmax(q K_dlt^T /sqrt d) V_dlt (iff lambda != 0)  tokens [32,48)
+ * three independent softmaxes; gates are read from device memory (gates[0]=anat, gates[1]=dis).
+ * Replaces SplitInjectionAttentionProcessor.__call__ lines 142-181 and
+ * OrdinalIPAttnProcessor2_0.__call__ lines 92-122 (src/models/attention_processor_*.py). */
+int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* gates, float lambda,
+                       int mode, int B, int N, int heads, int d, int T, int ld_kv, void* stream);
+
+/* ---- sampler glue --------------------------------------------------------------------------
+ * Sinusoidal timestep features (flip_sin_to_cos, shift 0): out[m][0:dim/2]=cos, [dim/2:]=sin. */
+int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream);
+/* out[m][n] = act_out( sum_k act_in(x[m][k]) * w[n][k] + bias[n] ), fp32 rows, fp16 weights,
+ * M small (time-embedding MLP, per-resblock time_emb_proj).  act: 0 none, 1 SiLU. */
+int dadd_linear_rows_f32(const float* x, const void* w, const float* bias, float* out, int M, int K,
+                         int N, int act_in, int act_out, void* stream);
+/* Per-step prologue run from inside the captured graph: row = *step;
+ * cur_rows[b][:] = table[row][:] for b < B; cur_coef[0:4] = coef[row][0:4]; then *step += 1. */
+int dadd_begin_step(const float* table, float* cur_rows, int B, int ncols, const float* coef,
+                    float* cur_coef, int32_t* step, void* stream);
+/* DDIM update (eta = 0), op-for-op as inference_pipeline_ip.py:430-456:
+ * eps = eps_u + g*(eps_c-eps_u) when eps_u != NULL; x0 = clamp((x - c1*eps)/c0, -4, 4);
+ * x = last ? x0 : c2*x0 + c3*eps   with coef = {sqrt(ab_t), sqrt(1-ab_t), sqrt(ab_prev),
+ * sqrt(1-ab_prev)} and last encoded as c2 < 0. */
+int dadd_ddim_update_f32(float* x, const float* eps_c, const float* eps_u, float guidance,
+                         const float* coef, int64_t n, void* stream);
+
+/* ---- hipGraph capture of the step loop ----------------------------------------------------- */
+int dadd_graph_begin(void* stream);
+int dadd_graph_end(void* stream, void** graph_exec_out);
+int dadd_graph_launch(void* graph_exec, void* stream);
+int dadd_graph_destroy(void* graph_exec);
+
+/* ---- in-library HIP-event timing of one kernel family (bench.py roofline) -------------------
+ * kind 1 = implicit GEMM.  While enabled (eager launches only, never during capture) every
+ * launch of that family is bracketed by events on its own stream.  dadd_prof_end fills
+ * out[0]=launches, out[1]=total ms, out[2]=total algorithmic flop (2*M*N*K). */
+int dadd_prof_begin(int kind);
+int dadd_prof_end(double out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DADD_HIP_H */

@@ -1,0 +1,190 @@
+"""Operator backend: torch tensors in, C-ABI kernel launches out.
+
+``HipBackend`` is the only backend the product ships.  Every method takes device tensors whose
+memory torch owns, validates what the kernels assume, and launches on the backend's stream.
+(The engine takes the backend as a constructor argument so that the CPU test-suite can check the
+*wiring* of the plan with a reference implementation that lives under ``tests/``; the product
+never constructs anything but ``HipBackend`` and fails loudly when the library is missing.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    name = "hip-gfx950"
+
+    def __init__(self, device: torch.device):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBackend needs a ROCm device (torch.cuda.is_available() is False)")
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._desc = L.IgemmDesc()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.dadd_init())
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def s(self):
+        return self.stream.cuda_stream
+
+    def ctx(self):
+        """All torch-side work of the engine (allocation, copy_, zero_) runs on the backend stream,
+        so the caching allocator and the kernels agree on one stream order."""
+        return torch.cuda.stream(self.stream)
+
+    def empty(self, shape, dtype):
+        with self.ctx():
+            return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        with self.ctx():
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t: torch.Tensor, dtype=None):
+        with self.ctx():
+            return t.to(device=self.device, dtype=dtype or t.dtype).contiguous()
+
+    def copy_(self, dst: torch.Tensor, src: torch.Tensor):
+        with self.ctx():
+            dst.copy_(src.reshape(dst.shape))
+
+    def zero_(self, t: torch.Tensor):
+        with self.ctx():
+            t.zero_()
+
+    def clone(self, t: torch.Tensor):
+        with self.ctx():
+            return t.detach().clone()
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def wait_current(self):
+        """Order this backend's stream after torch's current stream (inputs produced by torch ops)."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def release_to_current(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    # ------------------------------------------------------------------ ops
+    def pack_latents(self, x, out, scale=1.0, mat=None, vec=None):
+        b, c, h, w = x.shape
+        assert x.dtype == torch.float32 and out.dtype == torch.float16 and out.shape == (b, h, w, 8)
+        L.check(self.lib.dadd_pack_nchw_f32_to_nhwc8_f16(_p(x), _p(out), b, c, h, w, float(scale),
+                                                         _p(mat), _p(vec), self.s))
+
+    def conv_cin8(self, x, w, bias, out):
+        b, h, wd, c8 = x.shape
+        assert c8 == 8 and w.shape[1:] == (9, 8) and out.shape == (b, h, wd, w.shape[0])
+        L.check(self.lib.dadd_conv3x3_cin8_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, w.shape[0],
+                                               self.s))
+
+    def conv_cout4(self, x, w, bias, out, mode=0):
+        b, h, wd, c = x.shape
+        co = w.shape[0]
+        assert w.shape == (co, 9, c) and out.shape == (b, co, h, wd) and out.dtype == torch.float32
+        L.check(self.lib.dadd_conv3x3_cout4_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, c, co,
+                                                int(mode), self.s))
+
+    def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
+              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0):
+        """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU)."""
+        b, hi, wi, c1 = x.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        n = w.shape[0]
+        ho, wo = out.shape[1], out.shape[2]
+        assert w.shape[1] == taps * (c1 + c2), (w.shape, taps, c1, c2)
+        assert out.shape[-1] == (n // 2 if flags & L.EPI_GEGLU else n) and out.shape[0] == b
+        d = self._desc
+        d.x, d.x2, d.w, d.out, d.partial = _p(x), _p(x2), _p(w), _p(out), _p(partial)
+        d.bias, d.rowvec, d.residual = _p(bias), _p(rowvec), _p(residual)
+        d.B, d.Hi, d.Wi, d.C1, d.C2, d.Ho, d.Wo, d.N = b, hi, wi, c1, c2, ho, wo, n
+        d.taps, d.stride, d.ups, d.pad = taps, stride, ups, pad
+        d.ldo, d.ldr = out.stride(-2), (residual.stride(-2) if residual is not None else 0)
+        d.ld_rowvec = rowvec.stride(0) if rowvec is not None else 0
+        d.splitk, d.flags, d.tile_n = splitk, flags, tile_n
+        if partial is not None:
+            assert partial.numel() >= splitk * b * ho * wo * n
+        L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))
+
+    def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu):
+        b = x1.shape[0]
+        hw = x1.shape[1] * x1.shape[2]
+        c1 = x1.shape[-1]
+        c2 = 0 if x2 is None else x2.shape[-1]
+        assert out.shape[-1] == c1 + c2 and ws.numel() >= b * L.GN_MAX_CHUNKS * groups * 2
+        L.check(self.lib.dadd_groupnorm_f16(_p(x1), c1, _p(x2), c2, _p(gamma), _p(beta), _p(out),
+                                            _p(ws), b, hw, groups, float(eps), int(silu), self.s))
+
+    def layernorm(self, x, gamma, beta, out, eps=1e-5):
+        c = x.shape[-1]
+        m = x.numel() // c
+        L.check(self.lib.dadd_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), m, c, float(eps),
+                                            self.s))
+
+    def self_attn(self, qkv, out, heads):
+        """qkv [B,N,3C] (q|k|v blocks of C columns); out [B,N,C]."""
+        b, n, c3 = qkv.shape
+        c = c3 // 3
+        base = qkv.data_ptr()
+        L.check(self.lib.dadd_self_attn_f16(base, base + 2 * c, base + 4 * c, _p(out), b, n, heads,
+                                            c // heads, c3, out.stride(-2), self.s))
+
+    def tri_xattn(self, q, kv, out, gates, lam, mode, heads):
+        b, n, c = q.shape
+        L.check(self.lib.dadd_tri_xattn_f16(_p(q), _p(kv), _p(out), _p(gates), float(lam), int(mode),
+                                            b, n, heads, c // heads, kv.shape[1], kv.stride(1),
+                                            self.s))
+
+    def timestep_features(self, t, out):
+        assert t.dtype == torch.int64 and out.dtype == torch.float32
+        L.check(self.lib.dadd_timestep_features_f32(_p(t), _p(out), out.shape[0], out.shape[1], self.s))
+
+    def linear_rows(self, x, w, bias, out, act_in=0, act_out=0):
+        m, k = x.shape
+        n = w.shape[0]
+        assert w.shape[1] == k and out.shape == (m, n) and x.dtype == torch.float32
+        L.check(self.lib.dadd_linear_rows_f32(_p(x), _p(w), _p(bias), _p(out), m, k, n, act_in,
+                                              act_out, self.s))
+
+    def begin_step(self, table, cur_rows, coef, cur_coef, step):
+        L.check(self.lib.dadd_begin_step(_p(table), _p(cur_rows), cur_rows.shape[0], table.shape[1],
+                                         _p(coef), _p(cur_coef), _p(step), self.s))
+
+    def ddim_update(self, x, eps_c, eps_u, guidance, coef):
+        L.check(self.lib.dadd_ddim_update_f32(_p(x), _p(eps_c), _p(eps_u), float(guidance), _p(coef),
+                                              x.numel(), self.s))
+
+    # ------------------------------------------------------------------ graphs / profiling
+    def graph_begin(self):
+        L.check(self.lib.dadd_graph_begin(self.s))
+
+    def graph_end(self):
+        g = C.c_void_p()
+        L.check(self.lib.dadd_graph_end(self.s, C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        L.check(self.lib.dadd_graph_launch(g, self.s))
+
+    def graph_destroy(self, g):
+        L.check(self.lib.dadd_graph_destroy(g))
+
+    def prof_begin(self, kind=1):
+        L.check(self.lib.dadd_prof_begin(kind))
+
+    def prof_end(self):
+        out = (C.c_double * 3)()
+        L.check(self.lib.dadd_prof_end(out))
+        return {"launches": int(out[0]), "ms": out[1], "flop": out[2]}

@@ -1,0 +1,491 @@
+// Attention on gfx950 MFMA.
+//
+// Both kernels compute the TRANSPOSED score tile  S^T = K * Q^T  (keys on the MFMA rows, queries on
+// the lanes): a lane then owns one query column, so the row-wise softmax needs only two xor
+// shuffles (lanes +16, +32) and the probabilities come out of the accumulator already shaped as the
+// B operand of the next product  O^T = V^T * P^T  (the contraction index — the key — may be
+// permuted freely as long as both operands use the same permutation: slot (g,j) of a 32-key step is
+// key 4g+j of the first 16-key fragment for j<4 and key 4g+j-4 of the second for j>=4).  V stays
+// row-major in LDS and is read transposed by ds_read_b64_tr_b16.  No score matrix, no P round trip.
+//
+//  * flash_kernel   : self-attention, online softmax over 64-key tiles (attn1, VAE mid block)
+//  * xattn_kernel   : the DADD cross-attention — 2 or 3 sixteen-key pathways with INDEPENDENT
+//                     softmaxes, gate/lambda folded into the probabilities, K/V fragments resident
+//                     in registers for the whole block (they are step-invariant and tiny)
+#include "dadd_common.h"
+
+namespace {
+
+constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// V row stride (halfs) such that 8 consecutive rows x 32 B hit distinct banks for the tr reads.
+constexpr int v_stride(int dvp) { return ((dvp * 2) % 64 == 32) ? dvp : dvp + 16; }
+
+__device__ __forceinline__ h8 tr_pair(const half_t* lds_row_lo, const half_t* lds_row_hi) {
+  typedef __attribute__((address_space(3))) fp16x4 lds_v4;
+  const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4*)lds_row_lo);
+  const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4*)lds_row_hi);
+  h8 r;
+  r[0] = (half_t)a[0]; r[1] = (half_t)a[1]; r[2] = (half_t)a[2]; r[3] = (half_t)a[3];
+  r[4] = (half_t)b[0]; r[5] = (half_t)b[1]; r[6] = (half_t)b[2]; r[7] = (half_t)b[3];
+  return r;
+}
+
+__device__ __forceinline__ h8 pack_p(const f4& lo, const f4& hi) {
+  h8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[j] = (half_t)lo[j];
+    r[j + 4] = (half_t)hi[j];
+  }
+  return r;
+}
+
+struct FlashArgs {
+  const half_t* q;
+  const half_t* k;
+  const half_t* v;
+  half_t* out;
+  int B, N, H, ld, ldo;
+  float scale_log2;  // log2(e)/sqrt(d)
+};
+
+// DR = real head dim. Block = 4 waves x (16*QF) queries; KV tile = 64 keys.
+template <int DR, int QF, bool PREFETCH>
+__global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
+  constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
+  constexpr int KS = D / 32, DF = DVP / 16, DC = DR / 8;
+  constexpr int KLD = D + 8, VLD = v_stride(DVP);
+  constexpr int NL = (64 * DC + 255) / 256;  // 16-byte loads per thread per tile per tensor
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ks = reinterpret_cast<half_t*>(smem);
+  half_t* Vs = Ks + 64 * KLD;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int qw0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+  const size_t tok0 = (size_t)b * p.N;
+  const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // zero the padding columns once (K: [DR,D), V: [DR,DVP)); tile stores never touch them
+  for (int i = t; i < 64 * KLD / 8; i += 256) *reinterpret_cast<h8*>(Ks + i * 8) = zero8;
+  for (int i = t; i < 64 * VLD / 8; i += 256) *reinterpret_cast<h8*>(Vs + i * 8) = zero8;
+
+  // Q fragments (B operand of S^T = K Q^T): lane -> query li, d-chunk 32s + 8g
+  h8 qf[QF][KS];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    int qrow = qw0 + f * 16 + li;
+    if (qrow > p.N - 1) qrow = p.N - 1;
+    const half_t* qp = p.q + (tok0 + qrow) * p.ld + h * DR;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int dc = 32 * s + 8 * g;
+      qf[f][s] = (dc < DR) ? *reinterpret_cast<const h8*>(qp + dc) : zero8;
+    }
+  }
+
+  f4 oacc[DF][QF];
+  float mrow[QF], lrow[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    mrow[f] = -1e30f;
+    lrow[f] = 0.f;
+#pragma unroll
+    for (int df = 0; df < DF; ++df) oacc[df][f] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nkt = (p.N + 63) / 64;
+  h8 rk[PREFETCH ? NL : 1], rv[PREFETCH ? NL : 1];
+
+  auto tile_load = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = t + 256 * u;
+      const int row = idx / DC, ch = idx - row * DC;
+      const int key = kt * 64 + row;
+      const bool ok = (idx < 64 * DC) & (key < p.N);
+      const size_t off = (tok0 + key) * p.ld + h * DR + ch * 8;
+      rk[u] = ok ? *reinterpret_cast<const h8*>(p.k + off) : zero8;
+      rv[u] = ok ? *reinterpret_cast<const h8*>(p.v + off) : zero8;
+    }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = t + 256 * u;
+      const int row = idx / DC, ch = idx - row * DC;
+      if (idx < 64 * DC) {
+        *reinterpret_cast<h8*>(Ks + row * KLD + ch * 8) = rk[u];
+        *reinterpret_cast<h8*>(Vs + row * VLD + ch * 8) = rv[u];
+      }
+    }
+  };
+  auto tile_direct = [&](int kt) {  // no register staging across the compute phase (large DR)
+    for (int idx = t; idx < 64 * DC; idx += 256) {
+      const int row = idx / DC, ch = idx - row * DC;
+      const int key = kt * 64 + row;
+      const size_t off = (tok0 + key) * p.ld + h * DR + ch * 8;
+      const bool ok = key < p.N;
+      *reinterpret_cast<h8*>(Ks + row * KLD + ch * 8) =
+          ok ? *reinterpret_cast<const h8*>(p.k + off) : zero8;
+      *reinterpret_cast<h8*>(Vs + row * VLD + ch * 8) =
+          ok ? *reinterpret_cast<const h8*>(p.v + off) : zero8;
+    }
+  };
+
+  if (PREFETCH) tile_load(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // everyone finished reading the previous tile (and the initial zero fill)
+    if (PREFETCH) tile_store(); else tile_direct(kt);
+    __syncthreads();
+    if (PREFETCH && kt + 1 < nkt) tile_load(kt + 1);
+
+    // ---- S^T = K Q^T : sacc[kf][f], rows = keys kf*16 + 4g + r, column = query li
+    f4 sacc[4][QF];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int f = 0; f < QF; ++f) sacc[kf][f] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) {
+        const h8 ka = *reinterpret_cast<const h8*>(Ks + (kf * 16 + li) * KLD + 32 * s + 8 * g);
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+          sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], sacc[kf][f], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax per query column
+    h8 pb[QF][2];
+    const int kbase = kt * 64 + 4 * g;
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sv = sacc[kf][f][r] * p.scale_log2;
+          if (kbase + kf * 16 + r >= p.N) sv = -1e30f;
+          sacc[kf][f][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrow[f], mx);
+      const float alpha = exp2f(mrow[f] - mnew);
+      float rs = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = exp2f(sacc[kf][f][r] - mnew);
+          sacc[kf][f][r] = pv;
+          rs += pv;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      lrow[f] = lrow[f] * alpha + rs;
+      mrow[f] = mnew;
+#pragma unroll
+      for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
+      pb[f][0] = pack_p(sacc[0][f], sacc[1][f]);
+      pb[f][1] = pack_p(sacc[2][f], sacc[3][f]);
+    }
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const half_t* base = Vs + (kb * 32 + 4 * g + (li >> 2)) * VLD + df * 16 + 4 * (li & 3);
+        const h8 va = tr_pair(base, base + 16 * VLD);
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+          oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[f][kb], oacc[df][f], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane owns O[q = li][d = df*16 + 4g .. +3]
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int qrow = qw0 + f * 16 + li;
+    if (qrow >= p.N) continue;
+    const float inv = 1.0f / lrow[f];
+    half_t* op = p.out + (tok0 + qrow) * p.ldo + h * DR;
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+      const int dcol = df * 16 + 4 * g;
+      if (dcol < DR) {
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(oacc[df][f][r] * inv);
+        *reinterpret_cast<h4*>(op + dcol) = o;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+struct XattnArgs {
+  const half_t* q;
+  const half_t* kv;
+  half_t* out;
+  const float* gates;
+  float lambda;
+  int B, N, H, T, ldkv, C;
+  float scale_log2;
+};
+
+// NF sixteen-key fragments; JOINT = one softmax over all of them (baseline) instead of one each.
+template <int DR, int NF, bool JOINT>
+__global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
+  constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
+  constexpr int KS = D / 32, DF = DVP / 16, DC = DR / 8;
+  constexpr int VLD = v_stride(DVP);
+  constexpr int KB = (NF + 1) / 2;  // 32-key steps of the PV product
+  __shared__ __attribute__((aligned(16))) half_t Vs[64 * VLD];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // fragment descriptors (wave-uniform)
+  int tb[NF], kcol[NF], vcol[NF];
+  float wgt[NF];
+  if (JOINT) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { tb[f] = 16 * f; kcol[f] = 0; vcol[f] = p.C; wgt[f] = 1.f; }
+  } else {
+    tb[0] = 16; kcol[0] = 0;       vcol[0] = p.C;     wgt[0] = p.gates[0];  // anatomy
+    tb[1] = 0;  kcol[1] = 2 * p.C; vcol[1] = 3 * p.C; wgt[1] = p.gates[1];  // disease
+    if (NF > 2) { tb[NF - 1] = 32; kcol[NF - 1] = 2 * p.C; vcol[NF - 1] = 3 * p.C; wgt[NF - 1] = p.lambda; }
+  }
+
+  // V rows -> LDS (row f*16 + key), rest zero so that empty key slots contribute exactly 0
+  for (int i = t; i < 64 * VLD / 8; i += 256) *reinterpret_cast<h8*>(Vs + i * 8) = zero8;
+  __syncthreads();
+  for (int idx = t; idx < NF * 16 * DC; idx += 256) {
+    const int row = idx / DC, ch = idx - row * DC;
+    const int f = row >> 4, key = row & 15;
+    const size_t off = ((size_t)b * p.T + tb[f] + key) * p.ldkv + vcol[f] + h * DR + ch * 8;
+    *reinterpret_cast<h8*>(Vs + row * VLD + ch * 8) = *reinterpret_cast<const h8*>(p.kv + off);
+  }
+  __syncthreads();
+
+  // resident operands: K fragments (A of S^T) straight from HBM, V^T fragments via tr reads
+  h8 kA[NF][KS];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const half_t* kp = p.kv + ((size_t)b * p.T + tb[f] + li) * p.ldkv + kcol[f] + h * DR;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int dc = 32 * s + 8 * g;
+      kA[f][s] = (dc < DR) ? *reinterpret_cast<const h8*>(kp + dc) : zero8;
+    }
+  }
+  h8 vA[DF][KB];
+#pragma unroll
+  for (int df = 0; df < DF; ++df)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const half_t* base = Vs + (kb * 32 + 4 * g + (li >> 2)) * VLD + df * 16 + 4 * (li & 3);
+      vA[df][kb] = tr_pair(base, base + 16 * VLD);
+    }
+
+  const size_t tok0 = (size_t)b * p.N;
+  const int q0 = blockIdx.x * 256;
+  for (int qfi = wave; qfi < 16; qfi += 4) {
+    const int qbase = q0 + qfi * 16;
+    if (qbase >= p.N) break;  // wave-uniform
+    int qrow = qbase + li;
+    const bool qok = qrow < p.N;
+    if (!qok) qrow = p.N - 1;
+    const half_t* qp = p.q + (tok0 + qrow) * p.C + h * DR;
+    h8 qB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int dc = 32 * s + 8 * g;
+      qB[s] = (dc < DR) ? *reinterpret_cast<const h8*>(qp + dc) : zero8;
+    }
+    f4 sacc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      sacc[f] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        sacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kA[f][s], qB[s], sacc[f], 0, 0, 0);
+    }
+    // softmax over the 16 keys of each fragment (or over all NF*16 when JOINT)
+    float mx[NF], sm[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      float m = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sacc[f][r] *= p.scale_log2;
+        m = fmaxf(m, sacc[f][r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      mx[f] = fmaxf(m, __shfl_xor(m, 32, 64));
+    }
+    if (JOINT) {
+      float m = mx[0];
+#pragma unroll
+      for (int f = 1; f < NF; ++f) m = fmaxf(m, mx[f]);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) mx[f] = m;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sacc[f][r] = exp2f(sacc[f][r] - mx[f]);
+        s += sacc[f][r];
+      }
+      s += __shfl_xor(s, 16, 64);
+      sm[f] = s + __shfl_xor(s, 32, 64);
+    }
+    if (JOINT) {
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) s += sm[f];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) sm[f] = s;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const float w = wgt[f] / sm[f];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sacc[f][r] *= w;
+    }
+    h8 pb[KB];
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+      pb[kb] = pack_p(sacc[2 * kb], (2 * kb + 1 < NF) ? sacc[(2 * kb + 1 < NF) ? 2 * kb + 1 : 0] : zero4);
+
+    half_t* op = p.out + (tok0 + qrow) * p.C + h * DR;
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+      f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vA[df][kb], pb[kb], o, 0, 0, 0);
+      const int dcol = df * 16 + 4 * g;
+      if (qok && dcol < DR) {
+        h4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (half_t)o[r];
+        *reinterpret_cast<h4*>(op + dcol) = ov;
+      }
+    }
+  }
+}
+
+template <int DR, int QF, bool PF>
+int flash_attr() {
+  constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
+  constexpr int smem = 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<DR, QF, PF>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  return DADD_OK;
+}
+
+template <int DR, int QF, bool PF>
+int launch_flash(const FlashArgs& a, hipStream_t s) {
+  constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
+  constexpr int smem = 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
+  dim3 grid((a.N + 64 * QF - 1) / (64 * QF), a.B * a.H);
+  hipLaunchKernelGGL((flash_kernel<DR, QF, PF>), grid, dim3(256), smem, s, a);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+template <int DR>
+int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
+  dim3 grid((a.N + 255) / 256, a.B * a.H);
+  if (mode == DADD_XATTN_BASELINE)
+    hipLaunchKernelGGL((xattn_kernel<DR, 2, true>), grid, dim3(256), 0, s, a);
+  else if (a.lambda != 0.0f)
+    hipLaunchKernelGGL((xattn_kernel<DR, 3, false>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((xattn_kernel<DR, 2, false>), grid, dim3(256), 0, s, a);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+}  // namespace
+
+int dadd_init_attention() {
+  int rc = flash_attr<40, 2, true>();
+  if (rc == DADD_OK) rc = flash_attr<80, 2, true>();
+  if (rc == DADD_OK) rc = flash_attr<160, 2, true>();
+  if (rc == DADD_OK) rc = flash_attr<512, 1, false>();
+  return rc;
+}
+
+extern "C" int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B,
+                                  int N, int heads, int d, int ld_qkv, int ld_out, void* stream) {
+  DADD_REQUIRE(q && k && v && out, "self_attn: null pointer");
+  DADD_REQUIRE(B > 0 && N > 0 && heads > 0, "self_attn: empty problem");
+  DADD_REQUIRE(ld_qkv % 8 == 0 && ld_out % 4 == 0 && ld_qkv >= heads * d && ld_out >= heads * d,
+               "self_attn: bad leading dimensions");
+  DADD_REQUIRE(dadd_aligned16(q) && dadd_aligned16(k) && dadd_aligned16(v) && dadd_aligned16(out),
+               "self_attn: pointers must be 16-byte aligned");
+  FlashArgs a;
+  a.q = static_cast<const half_t*>(q);
+  a.k = static_cast<const half_t*>(k);
+  a.v = static_cast<const half_t*>(v);
+  a.out = static_cast<half_t*>(out);
+  a.B = B; a.N = N; a.H = heads; a.ld = ld_qkv; a.ldo = ld_out;
+  a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (d) {
+    case 40: return launch_flash<40, 2, true>(a, s);
+    case 80: return launch_flash<80, 2, true>(a, s);
+    case 160: return launch_flash<160, 2, true>(a, s);
+    case 512: return launch_flash<512, 1, false>(a, s);
+    default:
+      dadd_set_error("self_attn: unsupported head dim %d (40, 80, 160, 512)", d);
+      return DADD_EINVAL;
+  }
+}
+
+extern "C" int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* gates,
+                                  float lambda, int mode, int B, int N, int heads, int d, int T,
+                                  int ld_kv, void* stream) {
+  DADD_REQUIRE(q && kv && out, "tri_xattn: null pointer");
+  DADD_REQUIRE(mode == DADD_XATTN_SPLIT || mode == DADD_XATTN_BASELINE, "tri_xattn: bad mode");
+  const int C = heads * d;
+  if (mode == DADD_XATTN_SPLIT) {
+    DADD_REQUIRE(gates != nullptr, "tri_xattn: split mode needs gates");
+    DADD_REQUIRE(T == 48 && ld_kv >= 4 * C, "tri_xattn: split mode needs T=48, ld_kv>=4C");
+  } else {
+    DADD_REQUIRE(T == 32 && ld_kv >= 2 * C, "tri_xattn: baseline mode needs T=32, ld_kv>=2C");
+  }
+  DADD_REQUIRE(B > 0 && N > 0 && ld_kv % 8 == 0, "tri_xattn: bad extents");
+  DADD_REQUIRE(dadd_aligned16(q) && dadd_aligned16(kv) && dadd_aligned16(out),
+               "tri_xattn: pointers must be 16-byte aligned");
+  XattnArgs a;
+  a.q = static_cast<const half_t*>(q);
+  a.kv = static_cast<const half_t*>(kv);
+  a.out = static_cast<half_t*>(out);
+  a.gates = gates;
+  a.lambda = lambda;
+  a.B = B; a.N = N; a.H = heads; a.T = T; a.ldkv = ld_kv; a.C = C;
+  a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (d) {
+    case 40: return launch_xattn<40>(a, mode, s);
+    case 80: return launch_xattn<80>(a, mode, s);
+    case 160: return launch_xattn<160>(a, mode, s);
+    default:
+      dadd_set_error("tri_xattn: unsupported head dim %d (40, 80, 160)", d);
+      return DADD_EINVAL;
+  }
+}

@@ -1,0 +1,298 @@
+// Thin-channel convolutions at the ends of the UNet / VAE, layout conversion, time-embedding
+// rows, and the DDIM update — the small HBM/latency-bound pieces around the MFMA kernels.
+#include "dadd_common.h"
+
+namespace {
+
+// fp32 NCHW (C<=8 real channels) -> fp16 NHWC8, optional per-pixel CxC matrix + bias, then scale
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ x, half_t* __restrict__ out,
+                                                   int B, int C, int HW, float scale,
+                                                   const float* __restrict__ mat,
+                                                   const float* __restrict__ vec) {
+  const size_t total = (size_t)B * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / HW, pix = i - b * HW;
+    float v[8], o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (c < C) ? x[(b * C + c) * HW + pix] * scale : 0.f;
+    if (mat) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a = 0.f;
+        if (c < C) {
+          a = vec ? vec[c] : 0.f;
+          for (int k = 0; k < C; ++k) a += mat[c * C + k] * v[k];
+        }
+        o[c] = a;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = v[c];
+    }
+    h8 r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = (half_t)o[c];
+    *reinterpret_cast<h8*>(out + i * 8) = r;
+  }
+}
+
+// conv3x3 pad1 from 8 stored channels: thread = (pixel, group of 8 output channels).  Consecutive
+// threads are consecutive pixels of one output-channel group, so the weights are wave-uniform.
+__global__ __launch_bounds__(256) void conv_cin8_kernel(const half_t* __restrict__ x,
+                                                        const half_t* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        half_t* __restrict__ out, int B, int H, int W,
+                                                        int Cout) {
+  const int npix = B * H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int co0 = blockIdx.y * 8;
+  if (pix >= npix) return;
+  const int b = pix / (H * W), rem = pix - b * H * W, oy = rem / W, ox = rem - oy * W;
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = bias ? bias[co0 + o] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const h8 xv = *reinterpret_cast<const h8*>(x + ((size_t)(b * H + iy) * W + ix) * 8);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const h8 wv = *reinterpret_cast<const h8*>(w + ((size_t)(co0 + o) * 9 + tap) * 8);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[o] += (float)xv[c] * (float)wv[c];
+    }
+  }
+  h8 r;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) r[o] = (half_t)acc[o];
+  *reinterpret_cast<h8*>(out + (size_t)pix * Cout + co0) = r;
+}
+
+// conv3x3 pad1 to <=4 output channels: 16 lanes share one pixel (channel chunks of 8 strided over
+// the 16 lanes -> 256 contiguous bytes per tap), shuffle-reduced; fp32 NCHW output.
+__global__ __launch_bounds__(256) void conv_cout4_kernel(const half_t* __restrict__ x,
+                                                         const half_t* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ out, int B, int H, int W,
+                                                         int C, int Cout, int mode) {
+  const int npix = B * H * W;
+  const int sub = threadIdx.x & 15;
+  int pix = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = pix < npix;
+  if (!live) pix = npix - 1;
+  const int b = pix / (H * W), rem = pix - b * H * W, oy = rem / W, ox = rem - oy * W;
+  const int nchunk = C >> 3;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const half_t* xp = x + ((size_t)(b * H + iy) * W + ix) * C;
+    for (int ch = sub; ch < nchunk; ch += 16) {
+      const h8 xv = *reinterpret_cast<const h8*>(xp + ch * 8);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (o < Cout) {
+          const h8 wv = *reinterpret_cast<const h8*>(w + ((size_t)o * 9 + tap) * C + ch * 8);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[o] += (float)xv[c] * (float)wv[c];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+#pragma unroll
+    for (int s = 8; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s, 64);
+  }
+  if (live && sub < Cout) {
+    float v = acc[0];
+    if (sub == 1) v = acc[1];
+    if (sub == 2) v = acc[2];
+    if (sub == 3) v = acc[3];
+    v += bias ? bias[sub] : 0.f;
+    if (mode == 1) {
+      v = fminf(fmaxf(v, -1.f), 1.f);
+      v = (v + 1.f) / 2.f;
+      v = fminf(fmaxf(v, 0.f), 1.f);
+    }
+    out[((size_t)b * Cout + sub) * H * W + rem] = v;
+  }
+}
+
+__global__ void timestep_features_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int M,
+                                         int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * half) return;
+  const int m = i / half, j = i - m * half;
+  // freqs = exp(-ln(10000) * j / half), computed in fp32 like the reference engine
+  const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+  const float ang = (float)t[m] * freq;
+  out[(size_t)m * dim + j] = cosf(ang);
+  out[(size_t)m * dim + half + j] = sinf(ang);
+}
+
+// out[m][n] = act_out(sum_k act_in(x[m][k]) w[n][k] + bias[n]); one wave per output column,
+// up to 8 rows of x staged in LDS per pass.
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x,
+                                                          const half_t* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ out, int M, int K, int N,
+                                                          int act_in, int act_out) {
+  extern __shared__ float xs[];  // [8][K]
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nchunk = K >> 3;
+  for (int m0 = 0; m0 < M; m0 += 8) {
+    const int mr = min(8, M - m0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < mr * K; i += 256) {
+      float v = x[(size_t)m0 * K + i];
+      xs[i] = act_in ? dadd_silu(v) : v;
+    }
+    __syncthreads();
+    if (n >= N) continue;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+      const h8 wv = *reinterpret_cast<const h8*>(w + (size_t)n * K + ch * 8);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r < mr) {
+          const float* xr = xs + r * K + ch * 8;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[r] += xr[c] * (float)wv[c];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float s = wave_sum(acc[r]);
+      if (lane == 0 && r < mr) {
+        float v = s + (bias ? bias[n] : 0.f);
+        out[(size_t)(m0 + r) * N + n] = act_out ? dadd_silu(v) : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void begin_step_kernel(const float* __restrict__ table,
+                                                          float* __restrict__ cur, int B, int ncols,
+                                                          const float* __restrict__ coef,
+                                                          float* __restrict__ cur_coef,
+                                                          int32_t* __restrict__ step) {
+  const int row = *step;
+  for (int i = threadIdx.x; i < ncols; i += 1024) {
+    const float v = table[(size_t)row * ncols + i];
+    for (int b = 0; b < B; ++b) cur[(size_t)b * ncols + i] = v;
+  }
+  if (threadIdx.x < 4) cur_coef[threadIdx.x] = coef[row * 4 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) *step = row + 1;
+}
+
+// Every operation is an individually rounded fp32 op in the reference's order (no FMA contraction).
+__global__ __launch_bounds__(256) void ddim_kernel(float* __restrict__ x, const float* __restrict__ ec,
+                                                   const float* __restrict__ eu, float g,
+                                                   const float* __restrict__ coef, int64_t n) {
+  const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float e = ec[i];
+    if (eu) {
+      const float u = eu[i];
+      e = __fadd_rn(u, __fmul_rn(g, __fsub_rn(e, u)));
+    }
+    float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c1, e)), c0);
+    x0 = fminf(fmaxf(x0, -4.0f), 4.0f);
+    x[i] = (c2 < 0.f) ? x0 : __fadd_rn(__fmul_rn(c2, x0), __fmul_rn(c3, e));
+  }
+}
+
+}  // namespace
+
+extern "C" int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B, int C, int H, int W,
+                                               float scale, const float* mat, const float* vec,
+                                               void* stream) {
+  DADD_REQUIRE(x && out, "pack: null pointer");
+  DADD_REQUIRE(B > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "pack: C must be in 1..8");
+  DADD_REQUIRE(dadd_aligned16(out), "pack: out must be 16-byte aligned");
+  const size_t total = (size_t)B * H * W;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     static_cast<half_t*>(out), B, C, H * W, scale, mat, vec);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* bias, void* out, int B,
+                                     int H, int W, int Cout, void* stream) {
+  DADD_REQUIRE(x && w && out, "conv_cin8: null pointer");
+  DADD_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "conv_cin8: Cout must be x8");
+  DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(w) && dadd_aligned16(out),
+               "conv_cin8: pointers must be 16-byte aligned");
+  const int npix = B * H * W;
+  hipLaunchKernelGGL(conv_cin8_kernel, dim3((npix + 255) / 256, Cout / 8), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w), bias, static_cast<half_t*>(out), B, H, W, Cout);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw,
+                                      int B, int H, int W, int C, int Cout, int mode, void* stream) {
+  DADD_REQUIRE(x && w && out_nchw, "conv_cout4: null pointer");
+  DADD_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && Cout >= 1 && Cout <= 4,
+               "conv_cout4: C must be x8 and Cout in 1..4");
+  DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(w), "conv_cout4: pointers must be 16-byte aligned");
+  const int npix = B * H * W;
+  hipLaunchKernelGGL(conv_cout4_kernel, dim3((npix + 15) / 16), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x),
+                     static_cast<const half_t*>(w), bias, out_nchw, B, H, W, C, Cout, mode);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream) {
+  DADD_REQUIRE(t && out && M > 0 && dim > 0 && dim % 2 == 0, "timestep_features: bad arguments");
+  const int n = M * dim / 2;
+  hipLaunchKernelGGL(timestep_features_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), t, out, M, dim);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_linear_rows_f32(const float* x, const void* w, const float* bias, float* out, int M,
+                                    int K, int N, int act_in, int act_out, void* stream) {
+  DADD_REQUIRE(x && w && out, "linear_rows: null pointer");
+  DADD_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && K <= 2048, "linear_rows: K must be x8, <=2048");
+  DADD_REQUIRE(dadd_aligned16(w), "linear_rows: w must be 16-byte aligned");
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((N + 3) / 4), dim3(256), (size_t)8 * K * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, static_cast<const half_t*>(w), bias, out, M,
+                     K, N, act_in, act_out);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_begin_step(const float* table, float* cur_rows, int B, int ncols, const float* coef,
+                               float* cur_coef, int32_t* step, void* stream) {
+  DADD_REQUIRE(table && cur_rows && coef && cur_coef && step && B > 0 && ncols > 0,
+               "begin_step: bad arguments");
+  hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     table, cur_rows, B, ncols, coef, cur_coef, step);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_ddim_update_f32(float* x, const float* eps_c, const float* eps_u, float guidance,
+                                    const float* coef, int64_t n, void* stream) {
+  DADD_REQUIRE(x && eps_c && coef && n > 0, "ddim_update: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ddim_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     eps_c, eps_u, guidance, coef, n);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}

@@ -1,0 +1,346 @@
+// Implicit-GEMM convolution / linear on gfx950 MFMA (v_mfma_f32_16x16x32_f16).
+//
+//   out[m][n] = epi( sum_k A[m][k] * W[n][k] ),  m = output pixel (NHWC row), k = (tap, cin)
+//
+// Block = 256 threads = 4 waves (2 along M x 2 along N); tile 128 x BN x 64 with BN = 128 or 160
+// (every UNet width is a multiple of 160, every VAE width a multiple of 128).  Both operands are
+// K-contiguous in HBM (NHWC activations, [Cout][tap][Cin] weights), so both are staged with 16-byte
+// loads into an XOR-swizzled LDS image and read back as ds_read_b128 MFMA fragments without bank
+// conflicts.  The next K tile is fetched into registers while the current one feeds the MFMAs
+// (double-buffered LDS, one barrier per K tile).  The MFMA is issued "swapped" (weights as the A
+// operand) so each lane ends up with 4 consecutive output channels of one pixel: 8-byte fp16
+// stores and vector reads of bias / time-embedding row / residual in the epilogue.
+//
+// Zero padding, stride 2, the asymmetric VAE-encoder padding, nearest-2x upsampling and the
+// skip-connection concat are all folded into the A-tile address generation.
+#include "dadd_common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const half_t* x;
+  const half_t* x2;
+  const half_t* w;
+  half_t* out;
+  float* partial;
+  const float* bias;
+  const float* rowvec;
+  const half_t* residual;
+  int B, Hi, Wi, C1, C2, Ho, Wo, N;
+  int taps, stride, ups, pad;
+  int ldo, ldr, ld_rowvec;
+  int splitk, flags;
+  int M, K, nkt, kps, ntiles;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+
+// LDS image: rows of 64 halfs (8 chunks of 16 B); chunk index XORed with (row>>1)&7 so that the 16
+// rows one MFMA fragment reads at a fixed chunk land on 16 distinct 16-byte slots of the bank row.
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
+  constexpr int WN = BN / 2;       // columns per wave
+  constexpr int J = WN / 16;       // n-fragments per wave (4 or 5)
+  constexpr int NB = BN * 8 / 256; // 16-byte weight loads per thread per K tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* As = reinterpret_cast<half_t*>(smem);
+  half_t* Bs = As + 2 * BM * BK;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = blockIdx.x % p.ntiles, mt = blockIdx.x / p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int z = blockIdx.y;
+  const int kt0 = z * p.kps;
+  const int kt1 = min(p.nkt, kt0 + p.kps);
+  const int Cin = p.C1 + p.C2;
+  const int q = t & 7;
+  const int r0 = t >> 3;
+  const int Hv = p.ups ? 2 * p.Hi : p.Hi;
+  const int Wv = p.ups ? 2 * p.Wi : p.Wi;
+  const int HoWo = p.Ho * p.Wo;
+
+  int a_pix[4], a_y[4], a_x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HoWo;
+    const int rem = mm - b * HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    a_pix[i] = b * p.Hi * p.Wi;
+    a_y[i] = ok ? oy * p.stride - p.pad : -100000;  // invalid rows fail every bounds test
+    a_x[i] = ox * p.stride - p.pad;
+  }
+
+  f4 acc[J][4];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+
+  h8 ra[4], rb[NB];
+  const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto gload = [&](int kt) {
+    const int kk = kt * BK;
+    const int tap = kk / Cin;
+    const int c = kk - tap * Cin;
+    const int ky = (p.taps == 9) ? tap / 3 : 0;
+    const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
+    const bool second = c >= p.C1;
+    const half_t* src = second ? p.x2 : p.x;
+    const int cs = second ? p.C2 : p.C1;
+    const int cc = (second ? c - p.C1 : c) + q * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = a_y[i] + ky, ix = a_x[i] + kx;
+      const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
+      if (p.ups) {
+        iy >>= 1;
+        ix >>= 1;
+      }
+      const size_t off = (size_t)(a_pix[i] + iy * p.Wi + ix) * cs + cc;
+      ra[i] = ok ? *reinterpret_cast<const h8*>(src + off) : zero8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      rb[i] = (n < p.N) ? *reinterpret_cast<const h8*>(p.w + (size_t)n * p.K + kk + q * 8) : zero8;
+    }
+  };
+  auto lstore = [&](int buf) {
+    half_t* a = As + buf * BM * BK;
+    half_t* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<h8*>(a + lds_off(r0 + 32 * i, q)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<h8*>(b + lds_off(r0 + 32 * i, q)) = rb[i];
+  };
+  auto compute = [&](int buf) {
+    const half_t* a = As + buf * BM * BK;
+    const half_t* b = Bs + buf * BN * BK;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int chunk = s * 4 + (lane >> 4);
+      h8 xa[4], wb[J];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xa[i] = *reinterpret_cast<const h8*>(a + lds_off(wm * 64 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        wb[j] = *reinterpret_cast<const h8*>(b + lds_off(wn * WN + j * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
+    }
+  };
+
+  if (kt0 < kt1) {
+    gload(kt0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = kt + 1 < kt1;
+    if (more) gload(kt + 1);
+    compute(cur);
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds out[m][n .. n+3] for (i, j); m = column of the swapped MFMA result
+  const int g = lane >> 4, mc = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + mc;
+    if (m >= p.M) continue;
+    const int b = m / HoWo;
+    if (p.splitk > 1) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        if (n < p.N)
+          *reinterpret_cast<f4*>(p.partial + ((size_t)z * p.M + m) * p.N + n) = acc[j][i];
+      }
+      continue;
+    }
+    if (p.flags & DADD_EPI_GEGLU) {
+      if constexpr (J == 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int nh = n0 + wn * WN + j * 16 + g * 4;  // physical (interleaved) weight rows
+          const int ng = nh + 32;
+          if (ng >= p.N) continue;
+          f4 hv = acc[j][i], gv = acc[j + 2][i];
+          if (p.flags & DADD_EPI_BIAS) {
+            hv += *reinterpret_cast<const f4*>(p.bias + nh);
+            gv += *reinterpret_cast<const f4*>(p.bias + ng);
+          }
+          const int no = (n0 >> 1) + wn * 32 + j * 16 + g * 4;
+          h4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(hv[r] * dadd_gelu(gv[r]));
+          *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + no) = o;
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = n0 + wn * WN + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      f4 v = acc[j][i];
+      if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
+      if (p.flags & DADD_EPI_ROWVEC)
+        v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);
+      if (p.flags & DADD_EPI_RESIDUAL) {
+        const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      h4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+      *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
+    }
+  }
+}
+
+// Finishes a split-K launch: sums the fp32 slabs and applies the (non-GEGLU) epilogue.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, int nsplit) {
+  const int n4 = p.N >> 2;
+  const size_t total = (size_t)p.M * n4;
+  const int HoWo = p.Ho * p.Wo;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / n4);
+    const int n = (int)(idx - (size_t)m * n4) * 4;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s)
+      v += *reinterpret_cast<const f4*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
+    if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
+    if (p.flags & DADD_EPI_ROWVEC)
+      v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)(m / HoWo) * p.ld_rowvec + n);
+    if (p.flags & DADD_EPI_RESIDUAL) {
+      const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    h4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+    *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
+  }
+}
+
+template <int BN>
+int set_attr() {
+  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BN>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  return DADD_OK;
+}
+
+template <int BN>
+int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
+  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
+  const int mtiles = (a.M + BM - 1) / BM;
+  dim3 grid(mtiles * a.ntiles, nsplit);
+  hipLaunchKernelGGL(igemm_kernel<BN>, grid, dim3(256), smem, s, a);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+}  // namespace
+
+int dadd_init_igemm() {
+  int rc = set_attr<128>();
+  return rc != DADD_OK ? rc : set_attr<160>();
+}
+
+extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
+  DADD_REQUIRE(d != nullptr, "igemm: null descriptor");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  IgemmArgs a;
+  a.x = static_cast<const half_t*>(d->x);
+  a.x2 = static_cast<const half_t*>(d->x2);
+  a.w = static_cast<const half_t*>(d->w);
+  a.out = static_cast<half_t*>(d->out);
+  a.partial = d->partial;
+  a.bias = d->bias;
+  a.rowvec = d->rowvec;
+  a.residual = static_cast<const half_t*>(d->residual);
+  a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
+  a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
+  a.flags = d->flags;
+  const int Cin = a.C1 + a.C2;
+  const bool geglu = (a.flags & DADD_EPI_GEGLU) != 0;
+  a.ldo = d->ldo > 0 ? d->ldo : (geglu ? a.N / 2 : a.N);
+  a.ldr = d->ldr > 0 ? d->ldr : a.N;
+  a.ld_rowvec = d->ld_rowvec > 0 ? d->ld_rowvec : a.N;
+
+  DADD_REQUIRE(a.x && a.w && a.out, "igemm: null x/w/out");
+  DADD_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps must be 1 or 9, got %d", a.taps);
+  DADD_REQUIRE(a.B > 0 && a.Hi > 0 && a.Wi > 0 && a.Ho > 0 && a.Wo > 0 && a.N > 0,
+               "igemm: non-positive extent");
+  DADD_REQUIRE(Cin % 64 == 0 && a.C1 % 64 == 0 && a.C1 > 0,
+               "igemm: channels must be multiples of 64 (C1=%d C2=%d)", a.C1, a.C2);
+  DADD_REQUIRE(a.C2 == 0 || a.x2 != nullptr, "igemm: C2>0 needs x2");
+  DADD_REQUIRE(a.N % 8 == 0, "igemm: N must be a multiple of 8, got %d", a.N);
+  DADD_REQUIRE(a.stride == 1 || a.stride == 2, "igemm: stride must be 1 or 2");
+  DADD_REQUIRE(!(a.ups && (a.stride != 1 || a.taps != 9)), "igemm: ups needs a stride-1 3x3");
+  DADD_REQUIRE(dadd_aligned16(a.x) && dadd_aligned16(a.w) && dadd_aligned16(a.out) &&
+                   (a.x2 == nullptr || dadd_aligned16(a.x2)),
+               "igemm: pointers must be 16-byte aligned");
+  DADD_REQUIRE(!(a.flags & DADD_EPI_BIAS) || a.bias, "igemm: bias flag without bias");
+  DADD_REQUIRE(!(a.flags & DADD_EPI_ROWVEC) || a.rowvec, "igemm: rowvec flag without rowvec");
+  DADD_REQUIRE(!(a.flags & DADD_EPI_RESIDUAL) || a.residual, "igemm: residual flag without ptr");
+  DADD_REQUIRE(a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ld_rowvec % 4 == 0,
+               "igemm: leading dimensions must be multiples of 4");
+
+  a.M = a.B * a.Ho * a.Wo;
+  a.K = a.taps * Cin;
+  a.nkt = a.K / BK;
+  int tile_n = d->tile_n;
+  if (geglu) {
+    DADD_REQUIRE(a.N % 128 == 0 && (tile_n == 0 || tile_n == 128), "igemm: GEGLU needs N%%128==0");
+    tile_n = 128;
+  }
+  if (tile_n == 0) tile_n = (a.N % 160 == 0) ? 160 : 128;
+  DADD_REQUIRE(tile_n == 128 || tile_n == 160, "igemm: tile_n must be 128 or 160");
+  a.ntiles = (a.N + tile_n - 1) / tile_n;
+
+  int splitk = d->splitk > 1 ? d->splitk : 1;
+  if (splitk > a.nkt) splitk = a.nkt;
+  a.kps = (a.nkt + splitk - 1) / splitk;
+  const int nsplit = (a.nkt + a.kps - 1) / a.kps;
+  a.splitk = nsplit;
+  DADD_REQUIRE(nsplit == 1 || (a.partial != nullptr && !geglu),
+               "igemm: split-K needs a partial buffer and no GEGLU");
+
+  const bool prof = dadd_prof_active(1);
+  if (prof) dadd_prof_pre(s);
+  int rc = (tile_n == 160) ? launch<160>(a, nsplit, s) : launch<128>(a, nsplit, s);
+  if (prof) dadd_prof_post(s, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+  if (rc != DADD_OK) return rc;
+  if (nsplit > 1) {
+    const size_t total = (size_t)a.M * (a.N / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, nsplit);
+    DADD_LAUNCH_CHECK();
+  }
+  return DADD_OK;
+}

@@ -1,0 +1,246 @@
+// GroupNorm(+SiLU) over NHWC fp16 with a fused skip-concat, and LayerNorm — HBM-bound kernels:
+// 16-byte loads/stores, fp32 statistics, wavefront-shuffle / LDS reductions, no atomics (results
+// are bit-reproducible run to run).
+#include "dadd_common.h"
+
+namespace {
+
+constexpr int GN_MAXV = 2;  // 16-byte channel vectors per thread: C <= 8*256*2 = 4096
+
+struct GnArgs {
+  const half_t* x1;
+  const half_t* x2;
+  const float* gamma;
+  const float* beta;
+  half_t* out;
+  float* ws;  // [B][nchunk][groups][2]
+  int C1, C2, C, HW, groups, cg, nchunk, rows_per_chunk, TV, RP, silu;
+  float eps;
+};
+
+__device__ __forceinline__ h8 gn_load(const GnArgs& p, size_t pix, int c) {
+  return (c < p.C1) ? *reinterpret_cast<const h8*>(p.x1 + pix * p.C1 + c)
+                    : *reinterpret_cast<const h8*>(p.x2 + pix * p.C2 + (c - p.C1));
+}
+
+// pass 1: per (batch, row-chunk) partial sums per group.  grid (nchunk, B)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
+  extern __shared__ float sm[];  // [RP][C] sums, [RP][C] squares
+  const int t = threadIdx.x, tv = t % p.TV, tr = t / p.TV;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int row0 = chunk * p.rows_per_chunk;
+  const int row1 = min(p.HW, row0 + p.rows_per_chunk);
+  float s[GN_MAXV][8], ss[GN_MAXV][8];
+#pragma unroll
+  for (int u = 0; u < GN_MAXV; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[u][e] = ss[u][e] = 0.f;
+  const int nvec = p.C >> 3;
+  if (tr < p.RP) {
+    for (int row = row0 + tr; row < row1; row += p.RP) {
+      const size_t pix = (size_t)b * p.HW + row;
+#pragma unroll
+      for (int u = 0; u < GN_MAXV; ++u) {
+        const int v = tv + u * p.TV;
+        if (v < nvec) {
+          const h8 x = gn_load(p, pix, v * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)x[e];
+            s[u][e] += f;
+            ss[u][e] += f * f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GN_MAXV; ++u) {
+      const int v = tv + u * p.TV;
+      if (v < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sm[tr * p.C + v * 8 + e] = s[u][e];
+          sm[(p.RP + tr) * p.C + v * 8 + e] = ss[u][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (t < p.groups) {
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < p.RP; ++r)
+      for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
+        a += sm[r * p.C + c];
+        q += sm[(p.RP + r) * p.C + c];
+      }
+    float* w = p.ws + (((size_t)b * p.nchunk + chunk) * p.groups + t) * 2;
+    w[0] = a;
+    w[1] = q;
+  }
+}
+
+// pass 2: finish the statistics (double), fold gamma/beta into per-channel scale/shift, apply.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
+  extern __shared__ float sm[];  // [C] scale, [C] shift, [groups] mean, [groups] rstd
+  float* scale = sm;
+  float* shift = sm + p.C;
+  float* mean = sm + 2 * p.C;
+  float* rstd = mean + p.groups;
+  const int t = threadIdx.x, tv = t % p.TV, tr = t / p.TV;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  if (t < p.groups) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < p.nchunk; ++k) {
+      const float* w = p.ws + (((size_t)b * p.nchunk + k) * p.groups + t) * 2;
+      a += (double)w[0];
+      q += (double)w[1];
+    }
+    const double n = (double)p.HW * (double)p.cg;
+    const double mu = a / n;
+    double var = q / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[t] = (float)mu;
+    rstd[t] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  for (int c = t; c < p.C; c += 256) {
+    const int g = c / p.cg;
+    const float sc = rstd[g] * p.gamma[c];
+    scale[c] = sc;
+    shift[c] = p.beta[c] - mean[g] * sc;
+  }
+  __syncthreads();
+  if (tr >= p.RP) return;
+  const int nvec = p.C >> 3;
+  const int row0 = chunk * p.rows_per_chunk;
+  const int row1 = min(p.HW, row0 + p.rows_per_chunk);
+  for (int row = row0 + tr; row < row1; row += p.RP) {
+    const size_t pix = (size_t)b * p.HW + row;
+#pragma unroll
+    for (int u = 0; u < GN_MAXV; ++u) {
+      const int v = tv + u * p.TV;
+      if (v < nvec) {
+        const h8 x = gn_load(p, pix, v * 8);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)x[e] * scale[v * 8 + e] + shift[v * 8 + e];
+          if (p.silu) f = dadd_silu(f);
+          o[e] = (half_t)f;
+        }
+        *reinterpret_cast<h8*>(p.out + pix * p.C + v * 8) = o;
+      }
+    }
+  }
+}
+
+// LayerNorm: one wave per row, the row lives in registers (exact two-pass variance).
+constexpr int LN_MAXV = 4;  // C <= 8*64*4 = 2048
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        half_t* __restrict__ out, int M, int C,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = C >> 3;
+  const half_t* xr = x + (size_t)row * C;
+  h8 v[LN_MAXV];
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+      v[u] = *reinterpret_cast<const h8*>(xr + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += (float)v[u][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[u][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+      h8 o;
+      const f4 g0 = *reinterpret_cast<const f4*>(gamma + i * 8);
+      const f4 g1 = *reinterpret_cast<const f4*>(gamma + i * 8 + 4);
+      const f4 b0 = *reinterpret_cast<const f4*>(beta + i * 8);
+      const f4 b1 = *reinterpret_cast<const f4*>(beta + i * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)(((float)v[u][e] - mean) * rstd * g0[e] + b0[e]);
+        o[e + 4] = (half_t)(((float)v[u][e + 4] - mean) * rstd * g1[e] + b1[e]);
+      }
+      *reinterpret_cast<h8*>(out + (size_t)row * C + i * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
+                                  const float* gamma, const float* beta, void* out, float* ws,
+                                  int B, int HW, int groups, float eps, int silu, void* stream) {
+  const int C = C1 + C2;
+  DADD_REQUIRE(x1 && gamma && beta && out && ws, "groupnorm: null pointer");
+  DADD_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0, "groupnorm: C1/C2 must be x8");
+  DADD_REQUIRE(C2 == 0 || x2, "groupnorm: C2>0 needs x2");
+  DADD_REQUIRE(groups > 0 && groups <= 256 && C % groups == 0, "groupnorm: C %% groups != 0");
+  DADD_REQUIRE(C <= 8 * 256 * GN_MAXV, "groupnorm: C=%d too large", C);
+  DADD_REQUIRE(B > 0 && HW > 0, "groupnorm: empty input");
+  DADD_REQUIRE(dadd_aligned16(x1) && dadd_aligned16(out) && (!x2 || dadd_aligned16(x2)),
+               "groupnorm: pointers must be 16-byte aligned");
+  GnArgs p;
+  p.x1 = static_cast<const half_t*>(x1);
+  p.x2 = static_cast<const half_t*>(x2);
+  p.gamma = gamma;
+  p.beta = beta;
+  p.out = static_cast<half_t*>(out);
+  p.ws = ws;
+  p.C1 = C1; p.C2 = C2; p.C = C; p.HW = HW; p.groups = groups; p.cg = C / groups;
+  p.silu = silu; p.eps = eps;
+  const int nvec = C / 8;
+  p.TV = nvec < 256 ? nvec : 256;
+  p.RP = 256 / p.TV;
+  int nchunk = HW / 32;
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > DADD_GN_MAX_CHUNKS) nchunk = DADD_GN_MAX_CHUNKS;
+  p.rows_per_chunk = (HW + nchunk - 1) / nchunk;
+  p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t sm1 = (size_t)2 * p.RP * C * sizeof(float);
+  const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, B), dim3(256), sm1, s, p);
+  DADD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(p.nchunk, B), dim3(256), sm2, s, p);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out,
+                                  int M, int C, float eps, void* stream) {
+  DADD_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
+  DADD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV,
+               "layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXV);
+  DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(out) && dadd_aligned16(gamma) &&
+                   dadd_aligned16(beta), "layernorm: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), gamma, beta,
+                     static_cast<half_t*>(out), M, C, eps);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}

@@ -1,0 +1,345 @@
+"""``DiffusionModuleWithIP`` with the attribute protocol the reference pipelines use, backed by the
+HIP engine.  Mirrors src/models/diffusion_module_ip.py (config block :33-64, construction :81-201,
+schedule :274-287, ``_get_image_embeds`` :315-332, ``forward`` :383-390) and the two thin wrappers
+src/models/unet/unet.py:52-146 and src/models/vae/vae.py:32-112.
+
+What callers touch and where it lives here:
+  module(latents, t, cond)           -> UNetPlan.forward              (eps, fp32 NCHW)
+  module.diff_cfg / module.cfg       -> DiffusionIPConfig / AttrDict
+  module.alphas_cumprod[...]         -> fp32 tensor, linear-beta schedule
+  module.ordinal_embedder(...)       -> conditioning.AdditiveOrdinalEmbedder
+  module._get_image_embeds(x)        -> CLIP tower + (Plus) projection
+  module.feature_purifier            -> conditioning.FeaturePurifier | None
+  module.unet.unet.named_modules()   -> 16 attn2 facades whose .processor.delta_scale is settable
+  module.vae.decode(x).sample        -> VaeDecoderPlan
+There is no CPU path: constructing the module needs the HIP library and a ROCm device.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Dict, Iterator, Optional, Tuple
+
+import torch
+
+from . import weights as W
+from .conditioning import (AdditiveOrdinalEmbedder, FeaturePurifier, ImageEncoder, ImageProjection,
+                           ImageProjectionPlus)
+from .engine import DdimLoop, UNetPlan, VaeDecoderPlan
+from .routing import get_block_type, get_frequency_mode_for_block
+
+
+@dataclass
+class DiffusionIPConfig:
+    num_train_timesteps: int
+    beta_start: float
+    beta_end: float
+    noise_schedule: str = "linear"
+    sampling_steps: int = 50
+    guidance_scale: float = 2.0
+    min_snr_gamma: float = 1.0
+    ema_update_interval: int = 10
+    latent_scale: float = 0.18215
+    input_perturbation: float = 0.0
+    image_encoder_path: str = "openai/clip-vit-base-patch16"
+    num_image_tokens: int = 16
+    num_aoe_tokens: int = 16
+    use_frequency_strategy: bool = True
+    use_image_projection_plus: bool = False
+    use_feature_purifier: bool = True
+    purifier_num_heads: int = 8
+    purifier_ff_mult: int = 2
+    delta_scale: float = 0.0
+    use_routing_gates: bool = True
+    gate_init_anatomy: tuple = (0.5, 0.5)
+    gate_init_disease: tuple = (0.5, 0.5)
+
+
+def diff_cfg_from(cfg: Any) -> DiffusionIPConfig:
+    g = getattr
+    m, d, t = cfg.model, cfg.diffusion, getattr(cfg, "training", SimpleNamespace())
+    return DiffusionIPConfig(
+        num_train_timesteps=d.num_train_timesteps, beta_start=d.beta_start, beta_end=d.beta_end,
+        noise_schedule=d.noise_schedule, sampling_steps=g(d, "sampling_steps", 50),
+        guidance_scale=g(d, "guidance_scale", 2.0), min_snr_gamma=g(d, "min_snr_gamma", 1.0),
+        ema_update_interval=g(d, "ema_update_interval", 10), latent_scale=g(d, "latent_scale", 0.18215),
+        input_perturbation=g(t, "input_perturbation", 0.0),
+        image_encoder_path=g(m, "image_encoder_path", "openai/clip-vit-base-patch16"),
+        num_image_tokens=g(m, "num_image_tokens", 16), num_aoe_tokens=g(m, "num_aoe_tokens", 16),
+        use_frequency_strategy=g(m, "use_frequency_strategy", True),
+        use_image_projection_plus=g(m, "use_image_projection_plus", False),
+        use_feature_purifier=g(m, "use_feature_purifier", True),
+        purifier_num_heads=g(m, "purifier_num_heads", 8), purifier_ff_mult=g(m, "purifier_ff_mult", 2),
+        delta_scale=g(m, "delta_scale", 0.0), use_routing_gates=g(m, "use_routing_gates", True),
+        gate_init_anatomy=tuple(g(m, "gate_init_anatomy", [0.5, 0.5])),
+        gate_init_disease=tuple(g(m, "gate_init_disease", [0.5, 0.5])))
+
+
+def build_noise_schedule(dc: DiffusionIPConfig) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Linear-in-beta schedule (NOT SD's scaled-linear), fp32 cumprod (:274-287)."""
+    if dc.noise_schedule != "linear":
+        raise NotImplementedError("Only linear noise schedule is supported.")
+    betas = torch.linspace(dc.beta_start, dc.beta_end, dc.num_train_timesteps, dtype=torch.float32)
+    return betas, torch.cumprod(1.0 - betas, dim=0)
+
+
+# ---------------------------------------------------------------------------------------------
+class _Processor:
+    """State holder of one attn2 site (what ``_set_delta_scale_on_processors`` walks)."""
+
+    def __init__(self, name: str, routing: bool, gates: Optional[torch.Tensor]):
+        self.name = name
+        if routing:
+            self.delta_scale = 0.0
+            self.block_type = get_block_type(name)
+            self.anat_gate, self.dis_gate = (gates[0], gates[1]) if gates is not None else (None, None)
+        else:
+            self.frequency_mode = get_frequency_mode_for_block(name)
+
+
+class _AttnSite:
+    def __init__(self, proc: _Processor):
+        self.processor = proc
+
+
+class _InnerUNet:
+    """Stands where diffusers' ``UNet2DConditionModel`` stands (``module.unet.unet``)."""
+
+    def __init__(self, plan: UNetPlan, routing: bool):
+        self._plan = plan
+        self.config = SimpleNamespace(in_channels=4, out_channels=4, cross_attention_dim=768,
+                                      block_out_channels=[320, 640, 1280, 1280], sample_size=64)
+        self._sites = {}
+        for site, _ in plan.sites:
+            n = f"{site}.transformer_blocks.0.attn2"
+            self._sites[n] = _AttnSite(_Processor(n, routing, plan.gates.get(site)))
+
+    def named_modules(self):
+        return iter(self._sites.items())
+
+    @property
+    def attn_processors(self):
+        return {n + ".processor": s.processor for n, s in self._sites.items()}
+
+    def delta_scale(self) -> float:
+        vals = {float(getattr(s.processor, "delta_scale", 0.0)) for s in self._sites.values()}
+        if len(vals) > 1:
+            raise ValueError(f"attention processors disagree on delta_scale: {sorted(vals)}")
+        return vals.pop()
+
+
+class OrdinalUNet:
+    """src/models/unet/unet.py:52-146: argument normalisation + sanity checks, then the engine."""
+
+    def __init__(self, plan: UNetPlan, routing: bool, conditioning_dim=768, in_channels=4, out_channels=4):
+        self.unet = _InnerUNet(plan, routing)
+        c = self.unet.config
+        if c.in_channels != in_channels:
+            raise ValueError(f"UNet in_channels mismatch: {c.in_channels} (from weights) vs {in_channels} (config).")
+        if c.out_channels != out_channels:
+            raise ValueError(f"UNet out_channels mismatch: {c.out_channels} (from weights) vs {out_channels} (config).")
+        if c.cross_attention_dim != conditioning_dim:
+            raise ValueError(f"UNet cross_attention_dim mismatch: {c.cross_attention_dim} (from weights) "
+                             f"vs {conditioning_dim} (config).")
+        self._plan = plan
+
+    def parameters(self) -> Iterator[torch.Tensor]:
+        return iter(self._plan.keep)
+
+    def __call__(self, latents, timesteps, cond_embed):
+        if cond_embed.ndim == 2:
+            cond_embed = cond_embed.unsqueeze(1)
+        elif cond_embed.ndim != 3:
+            raise ValueError(f"cond_embed must have shape (B, D) or (B, seq_len, D), got {cond_embed.shape}")
+        if timesteps.ndim == 0:
+            timesteps = timesteps[None]
+        elif timesteps.ndim > 1:
+            timesteps = timesteps.view(-1)
+        plan = self._plan
+        be = plan.be
+        be.wait_current()
+        # conditioning tensors are step-invariant: re-project only when the caller passes a new one
+        key = (cond_embed.data_ptr(), cond_embed._version, tuple(cond_embed.shape))
+        fresh = key != getattr(self, "_cond_key", None)
+        self._cond_key = key
+        eps = plan.forward(latents, timesteps.to(latents.device), cond_embed if fresh else None,
+                           lam=self.unet.delta_scale())
+        be.release_to_current()
+        return eps
+
+    forward = __call__
+
+
+class SDVAE:
+    """src/models/vae/vae.py:32-112 — decode() through the HIP decoder plan."""
+
+    def __init__(self, be, sd, batch, side, latent_scale):
+        self._be, self._sd = be, sd
+        self._plans: Dict[Tuple[int, int], VaeDecoderPlan] = {}
+        self._latent_scale = latent_scale
+        self._plan(batch, side)
+
+    def _plan(self, batch, side) -> VaeDecoderPlan:
+        p = self._plans.get((batch, side))
+        if p is None:
+            # the plan applies 1/latent_scale itself; decode() receives already-unscaled latents
+            p = VaeDecoderPlan(self._be, self._sd, batch, side, latent_scale=1.0)
+            self._plans[(batch, side)] = p
+        return p
+
+    def parameters(self):
+        return iter(next(iter(self._plans.values())).keep)
+
+    @torch.no_grad()
+    def decode(self, latents, *, return_dict: bool = True):
+        b, c, h, w = latents.shape
+        if c != 4 or h != w:
+            raise ValueError(f"latents must be (B, 4, S, S), got {tuple(latents.shape)}")
+        plan = self._plan(b, h)
+        be = self._be
+        be.wait_current()
+        be.copy_(plan.z_in, latents.float())
+        plan.run()
+        img = be.clone(plan.img_out)           # [0,1] frames; see sample_is_unit_range
+        be.release_to_current()
+        # The reference decoder returns [-1,1] and _latents_to_images maps to [0,1]; the HIP decoder
+        # fuses that tail into its last kernel, so hand back the equivalent [-1,1] tensor here.
+        out = img * 2.0 - 1.0
+        return SimpleNamespace(sample=out) if return_dict else out
+
+    def encode(self, images, *, return_dict: bool = True):
+        raise NotImplementedError("SDVAE.encode (training path, SURVEY.md §8 a15) is not built yet")
+
+
+class DiffusionModuleWithIP:
+    def __init__(self, cfg: Any, state_dict: Optional[Dict[str, torch.Tensor]] = None, *,
+                 device=None, seed: int = 0, batch_size: Optional[int] = None,
+                 clip_config: Optional[dict] = None, backend=None, warm_start_dis: bool = True):
+        from .backend import HipBackend
+        self.cfg = cfg
+        self.diff_cfg = diff_cfg_from(cfg)
+        dc = self.diff_cfg
+        betas, ac = build_noise_schedule(dc)      # raises NotImplementedError first, like the reference
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.be = backend if backend is not None else HipBackend(self.device)
+        self.training = False
+        routing = dc.use_routing_gates
+        gates = {"anatomy": dc.gate_init_anatomy, "disease": dc.gate_init_disease, "both": (0.5, 0.5)}
+        emb = cfg.model.ordinal_embedder
+        shapes = dict(W.unet_shapes(routing_gates=routing))
+        shapes.update(W.vae_shapes(encoder=False))
+        shapes.update(W.conditioning_shapes(
+            num_classes=emb.num_classes, dim=cfg.model.embedding_dim, num_tokens=dc.num_aoe_tokens,
+            clip_hidden=(clip_config or {}).get("hidden_size", 1024),
+            clip_proj=(clip_config or {}).get("projection_dim", 768),
+            projection_plus=dc.use_image_projection_plus, purifier=dc.use_feature_purifier,
+            purifier_ff_mult=dc.purifier_ff_mult))
+        if state_dict is None:
+            state_dict = W.init_state_dict(shapes, seed, gates=gates, warm_start_dis=warm_start_dis,
+                                           aoe_delta_scale=getattr(emb.aoe, "delta_scale", 0.1))
+        missing = [k for k in shapes if k not in state_dict]
+        if missing:
+            raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        self._sd = state_dict
+        self.latent_side = cfg.dataset.image_size // 8
+        self.batch_size = batch_size or 1
+
+        self.betas = betas.to(self.device)
+        self.alphas_cumprod = ac.to(self.device)
+        self.alphas_cumprod_prev = torch.cat([torch.ones(1), ac[:-1]]).to(self.device)
+        self.snr_values = (ac / (1.0 - ac + 1e-8)).to(self.device)
+
+        self.ordinal_embedder = AdditiveOrdinalEmbedder(
+            state_dict, self.device, emb.num_classes, cfg.model.embedding_dim, dc.num_aoe_tokens)
+        self.image_encoder = ImageEncoder(self.device, seed=seed, clip_config=clip_config)
+        proj_cls = ImageProjectionPlus if dc.use_image_projection_plus else ImageProjection
+        self.image_projection = proj_cls(state_dict, self.device, dc.num_image_tokens)
+        self.feature_purifier = (FeaturePurifier(state_dict, self.device, dc.purifier_num_heads)
+                                 if dc.use_feature_purifier else None)
+        self._unets: Dict[Tuple[int, int], OrdinalUNet] = {}
+        self._loops: Dict[Tuple[int, int], DdimLoop] = {}
+        self.unet = self._unet_for(self.batch_size, self.latent_side)
+        self.vae = SDVAE(self.be, state_dict, self.batch_size, self.latent_side, dc.latent_scale)
+
+    # ---- plans per (batch, side) ----------------------------------------------------------------
+    def _unet_for(self, batch: int, side: int) -> OrdinalUNet:
+        u = self._unets.get((batch, side))
+        if u is None:
+            dc = self.diff_cfg
+            plan = UNetPlan(self.be, self._sd, batch, side, use_routing_gates=dc.use_routing_gates,
+                            use_frequency_strategy=dc.use_frequency_strategy)
+            u = OrdinalUNet(plan, dc.use_routing_gates, self.cfg.model.conditioning_dim,
+                            self.cfg.model.latent_channels, self.cfg.model.latent_channels)
+            if self._unets:     # keep delta_scale consistent across plans
+                lam = next(iter(self._unets.values())).unet.delta_scale()
+                for _, s in u.unet.named_modules():
+                    if hasattr(s.processor, "delta_scale"):
+                        s.processor.delta_scale = lam
+            self._unets[(batch, side)] = u
+        return u
+
+    def ddim_loop(self, batch: int, side: int) -> DdimLoop:
+        lp = self._loops.get((batch, side))
+        if lp is None:
+            lp = DdimLoop(self._unet_for(batch, side)._plan)
+            self._loops[(batch, side)] = lp
+        return lp
+
+    # ---- reference protocol -----------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, cfg=None, weights_only=False, strict=False,
+                             map_location=None, **kw):
+        """Lightning ``.ckpt`` / plain state-dict loader.  Only loaders that execute nothing from the
+        file are used (``weights_only=True`` / safetensors) whatever the caller passes."""
+        path = str(checkpoint_path)
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path)
+        else:
+            blob = torch.load(path, map_location="cpu", weights_only=True)
+            sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+        if cfg is None:
+            raise ValueError("cfg is required (the reference stores it as a hyper-parameter)")
+        return cls(cfg, state_dict={k: v.float() for k, v in sd.items()}, **kw)
+
+    def to(self, *args, **kwargs):
+        for a in args:
+            if isinstance(a, (torch.device, str)) and torch.device(a).type != self.device.type:
+                raise RuntimeError(f"this module lives on {self.device}; there is no {a} path")
+        return self            # storage precision is fixed by the engine (fp16 tiles, fp32 accumulate)
+
+    def half(self):
+        return self
+
+    def float(self):
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def parameters(self):
+        yield from self.unet.parameters()
+        yield from self.ordinal_embedder.parameters()
+        yield from self.image_projection.parameters()
+        if self.feature_purifier is not None:
+            yield from self.feature_purifier.parameters()
+
+    def _get_image_embeds(self, structure_images: torch.Tensor) -> torch.Tensor:
+        if self.diff_cfg.use_image_projection_plus:
+            feats = self.image_encoder.get_hidden_states(structure_images)
+        else:
+            feats = self.image_encoder(structure_images)
+        return self.image_projection(feats)
+
+    def __call__(self, latents: torch.Tensor, timesteps: torch.Tensor, cond_embed: torch.Tensor):
+        b, _, s, _ = latents.shape
+        u = self._unet_for(b, s)
+        if u is not self.unet:          # processors of every plan follow the public one
+            lam = self.unet.unet.delta_scale()
+            for _, site in u.unet.named_modules():
+                if hasattr(site.processor, "delta_scale"):
+                    site.processor.delta_scale = lam
+        return u(latents, timesteps, cond_embed)
+
+    forward = __call__

@@ -1,0 +1,561 @@
+"""Static execution plans for the UNet epsilon-prediction, the VAE decoder and the DDIM loop.
+
+A plan is built once per (batch, latent side): weights are repacked into the kernels' layouts
+(fp16, ``[Cout][ky][kx][Cin]``), every intermediate gets a fixed buffer from a pool, and the
+operator sequence is recorded as a list of bound launches.  Running the plan allocates nothing and
+never synchronises, so one denoising step (``begin_step`` + UNet + DDIM update) is captured into a
+hipGraph and replayed ``steps`` times with a device-side step counter.
+
+What replaces what (reference paths):
+  * ``UNetPlan``      — ``DiffusionModuleWithIP.forward`` -> ``OrdinalUNet.forward`` ->
+                        diffusers ``UNet2DConditionModel`` (src/models/diffusion_module_ip.py:383-390,
+                        src/models/unet/unet.py:96-146) incl. the 16 attention processors
+                        (src/models/attention_processor_routing_gates.py:84-196 / _base.py:39-138)
+  * ``VaeDecoderPlan``— ``SDVAE.decode`` (src/models/vae/vae.py:90-112)
+  * ``DdimLoop``      — the loop body of ``_ddim_sample_ip``
+                        (src/pipelines/inference/inference_pipeline_ip.py:423-468)
+Step-invariant work is hoisted exactly: the K/V projections of the conditioning
+tokens (16 sites) and the whole time-embedding MLP + 22 ``time_emb_proj`` rows for all steps are
+computed once per sampling run.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import lib as L
+from .routing import get_block_type  # noqa: F401  (re-exported for callers)
+
+F16, F32 = torch.float16, torch.float32
+UNET_CH = (320, 640, 1280, 1280)
+VAE_CH = (128, 256, 512, 512)
+HEADS = 8
+GROUPS = 32
+N_CU = 256
+
+
+# ----------------------------------------------------------------------------- weight packing
+def pack_conv(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,kh,kw] (or [Cout,Cin]) fp32 -> [Cout, kh*kw*Cin] fp16, K = (tap, cin)."""
+    if w.dim() == 2:
+        return w.to(F16).contiguous()
+    co, ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).to(F16).contiguous()
+
+
+def pack_conv_cin8(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin<=8,3,3] -> [Cout,9,8] fp16, input channels zero-padded to 8."""
+    co, ci, _, _ = w.shape
+    out = torch.zeros(co, 9, 8, dtype=F16)
+    out[:, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(F16)
+    return out.contiguous()
+
+
+def pack_conv_cout4(w: torch.Tensor) -> torch.Tensor:
+    """[Cout<=4,C,3,3] -> [Cout,9,C] fp16."""
+    co, ci, _, _ = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, 9, ci).to(F16).contiguous()
+
+
+def geglu_interleave(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Row order for the fused GEGLU epilogue: every 128-row tile = 2 waves x [32 hidden | 32 gate]
+    rows of the same 32 output columns (diffusers GEGLU: ``hidden, gate = proj(x).chunk(2)``)."""
+    n2 = w.shape[0] // 2
+    idx = torch.arange(w.shape[0])
+    tile, r = idx // 128, idx % 128
+    wn, rr = r // 64, r % 64
+    col = tile * 64 + wn * 32 + (rr % 32)
+    src = torch.where(rr < 32, col, n2 + col)
+    return w[src].contiguous(), b[src].contiguous()
+
+
+def choose_splitk(m: int, n: int, k: int, tile_n: int) -> int:
+    """Split K when the output grid alone cannot fill the 256 CUs (low-resolution UNet levels)."""
+    tiles = math.ceil(m / 128) * math.ceil(n / tile_n)
+    nkt = k // 64
+    if tiles >= N_CU // 2 or nkt < 8:
+        return 1
+    want = math.ceil(N_CU / tiles)
+    return max(1, min(want, nkt // 4, 32))
+
+
+class Pool:
+    """Plan-time buffer pool: fixed addresses, explicit release, reuse by (shape, dtype)."""
+
+    def __init__(self, be):
+        self.be = be
+        self.free: Dict[Tuple, List[torch.Tensor]] = {}
+        self.bytes = 0
+
+    def get(self, shape, dtype=F16) -> torch.Tensor:
+        key = (tuple(shape), dtype)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        t = self.be.empty(shape, dtype)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def put(self, *ts):
+        for t in ts:
+            if t is not None:
+                self.free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+
+class _Plan:
+    def __init__(self, be):
+        self.be = be
+        self.pool = Pool(be)
+        self.ops: List = []
+        self.keep: List[torch.Tensor] = []  # weights & persistent buffers
+        self.gn_ws = None
+
+    def rec(self, fn, *a, **k):
+        self.ops.append((fn, a, k))
+
+    def run(self):
+        for fn, a, k in self.ops:
+            fn(*a, **k)
+
+    def dev(self, t, dtype=None):
+        d = self.be.to_device(t, dtype)
+        self.keep.append(d)
+        return d
+
+    # ---- recorded building blocks -----------------------------------------------------------
+    def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
+             stride=1, ups=0, pad=1, flags=0):
+        out = self.pool.get(out_shape)
+        n = w.shape[0]
+        tile_n = 128 if (flags & L.EPI_GEGLU) or n % 160 else 160
+        m = out_shape[0] * out_shape[1] * out_shape[2]
+        sk = 1 if flags & L.EPI_GEGLU else choose_splitk(m, n, w.shape[1], tile_n)
+        partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
+        f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
+            | (L.EPI_RESIDUAL if residual is not None else 0)
+        self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
+                 taps=taps, stride=stride, ups=ups, pad=pad, flags=f, splitk=sk, partial=partial,
+                 tile_n=tile_n)
+        self.pool.put(partial)
+        return out
+
+    def gn(self, x1, x2, gamma, beta, eps, silu):
+        c = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        out = self.pool.get((*x1.shape[:3], c))
+        self.rec(self.be.groupnorm, x1, x2, gamma, beta, out, self.gn_ws, GROUPS, eps, silu)
+        return out
+
+
+# ----------------------------------------------------------------------------- UNet
+class UNetPlan(_Plan):
+    """SD-1.x UNet forward for a fixed (B, S); eps = plan(latents) with cond/time prepared apart."""
+
+    def __init__(self, be, sd: Dict[str, torch.Tensor], batch: int, side: int, *,
+                 prefix="unet.unet", use_routing_gates=True, use_frequency_strategy=True):
+        super().__init__(be)
+        assert side % 8 == 0, "latent side must be a multiple of 8 (three stride-2 levels)"
+        self.B, self.S = batch, side
+        self.gates_mode = use_routing_gates
+        self.prefix = prefix + "."
+        self.sd = sd
+        self.lam = 0.0
+        self.gn_ws = be.empty((batch * L.GN_MAX_CHUNKS * GROUPS * 2,), F32)
+        u = self.prefix
+        # ---- time path: linear_1, linear_2, all 22 time_emb_proj concatenated
+        self.w_t1 = self.dev(sd[u + "time_embedding.linear_1.weight"], F16)
+        self.b_t1 = self.dev(sd[u + "time_embedding.linear_1.bias"])
+        self.w_t2 = self.dev(sd[u + "time_embedding.linear_2.weight"], F16)
+        self.b_t2 = self.dev(sd[u + "time_embedding.linear_2.bias"])
+        names = self._resnet_names()
+        self.temb_off, off = {}, 0
+        for nme in names:
+            self.temb_off[nme] = off
+            off += sd[u + nme + ".time_emb_proj.weight"].shape[0]
+        self.temb_cols = off
+        self.w_tp = self.dev(torch.cat([sd[u + n + ".time_emb_proj.weight"] for n in names]), F16)
+        self.b_tp = self.dev(torch.cat([sd[u + n + ".time_emb_proj.bias"] for n in names]))
+        self.temb_rows = be.zeros((batch, self.temb_cols), F32)     # current step's rows
+        # ---- cross-attention conditioning caches (step invariant)
+        self.sites = self._attn_sites()
+        self.T = 48 if use_routing_gates else 32
+        self.kv_w, self.kv, self.gates = {}, {}, {}
+        for site, c in self.sites:
+            ap = f"{u}{site}.transformer_blocks.0.attn2"
+            ws = [sd[ap + ".to_k.weight"], sd[ap + ".to_v.weight"]]
+            if use_routing_gates:
+                ws += [sd[ap + ".processor.to_k_dis.weight"], sd[ap + ".processor.to_v_dis.weight"]]
+                self.gates[site] = self.dev(torch.stack([sd[ap + ".processor.anat_gate"],
+                                                         sd[ap + ".processor.dis_gate"]]).float())
+            else:
+                self.gates[site] = None
+            self.kv_w[site] = self.dev(torch.cat(ws), F16)
+            self.kv[site] = [be.zeros((batch, 1, self.T, self.kv_w[site].shape[0]), F16)
+                             for _ in range(2)]                     # [cond, uncond]
+        self.cond16 = be.zeros((batch, 1, self.T, 768), F16)
+        self.kv_slot = 0
+        # ---- I/O
+        self.lat_in = be.zeros((batch, 4, side, side), F32)
+        self.eps_out = [be.zeros((batch, 4, side, side), F32) for _ in range(2)]
+        self._build()
+
+    # -- inventory -------------------------------------------------------------------------------
+    @staticmethod
+    def _resnet_names():
+        n = [f"down_blocks.{i}.resnets.{j}" for i in range(4) for j in range(2)]
+        n += ["mid_block.resnets.0", "mid_block.resnets.1"]
+        n += [f"up_blocks.{i}.resnets.{j}" for i in range(4) for j in range(3)]
+        return n
+
+    @staticmethod
+    def _attn_sites():
+        s = [(f"down_blocks.{i}.attentions.{j}", UNET_CH[i]) for i in range(3) for j in range(2)]
+        s.append(("mid_block.attentions.0", 1280))
+        s += [(f"up_blocks.{i}.attentions.{j}", UNET_CH[3 - i]) for i in (1, 2, 3) for j in range(3)]
+        return s
+
+    def w(self, key, pack=pack_conv):
+        return self.dev(pack(self.sd[self.prefix + key]))
+
+    def f(self, key):
+        return self.dev(self.sd[self.prefix + key].float())
+
+    # -- blocks ----------------------------------------------------------------------------------
+    def _resnet(self, name, x, skip=None):
+        b, h, w_, _ = x.shape
+        cin = x.shape[-1] + (0 if skip is None else skip.shape[-1])
+        cout = self.sd[self.prefix + name + ".conv1.weight"].shape[0]
+        off = self.temb_off[name]
+        g1 = self.gn(x, skip, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1)
+        h1 = self.conv(g1, self.w(name + ".conv1.weight"), (b, h, w_, cout),
+                       bias=self.f(name + ".conv1.bias"), rowvec=self.temb_rows[:, off:off + cout])
+        self.pool.put(g1)
+        g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1)
+        self.pool.put(h1)
+        if cin != cout:
+            res = self.conv(x, self.w(name + ".conv_shortcut.weight"), (b, h, w_, cout), x2=skip,
+                            bias=self.f(name + ".conv_shortcut.bias"), taps=1, pad=0)
+        else:
+            assert skip is None
+            res = x
+        out = self.conv(g2, self.w(name + ".conv2.weight"), (b, h, w_, cout),
+                        bias=self.f(name + ".conv2.bias"), residual=res)
+        self.pool.put(g2)
+        if res is not x:
+            self.pool.put(res)
+        return out
+
+    def _transformer(self, site, x):
+        b, h, w_, c = x.shape
+        shp = (b, h, w_, c)
+        tb = site + ".transformer_blocks.0"
+        g = self.gn(x, None, self.f(site + ".norm.weight"), self.f(site + ".norm.bias"), 1e-6, 0)
+        hs = self.conv(g, self.w(site + ".proj_in.weight"), shp, bias=self.f(site + ".proj_in.bias"),
+                       taps=1, pad=0)
+        self.pool.put(g)
+        ln = self.pool.get(shp)
+        # attn1 (self)
+        self.rec(self.be.layernorm, hs, self.f(tb + ".norm1.weight"), self.f(tb + ".norm1.bias"), ln)
+        wqkv = self.dev(torch.cat([self.sd[self.prefix + tb + f".attn1.to_{n}.weight"] for n in "qkv"]), F16)
+        qkv = self.conv(ln, wqkv, (b, h, w_, 3 * c), taps=1, pad=0)
+        att = self.pool.get(shp)
+        self.rec(self.be.self_attn, qkv.view(b, h * w_, 3 * c), att.view(b, h * w_, c), HEADS)
+        self.pool.put(qkv)
+        h2 = self.conv(att, self.w(tb + ".attn1.to_out.0.weight"), shp,
+                       bias=self.f(tb + ".attn1.to_out.0.bias"), residual=hs, taps=1, pad=0)
+        self.pool.put(hs)
+        # attn2 (DADD cross-attention)
+        self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
+        q = self.conv(ln, self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
+        self.rec(self._xattn, site, q.view(b, h * w_, c), att.view(b, h * w_, c))
+        self.pool.put(q)
+        h3 = self.conv(att, self.w(tb + ".attn2.to_out.0.weight"), shp,
+                       bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0)
+        self.pool.put(h2, att)
+        # GEGLU feed-forward
+        self.rec(self.be.layernorm, h3, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"), ln)
+        wf, bf = geglu_interleave(self.sd[self.prefix + tb + ".ff.net.0.proj.weight"],
+                                  self.sd[self.prefix + tb + ".ff.net.0.proj.bias"])
+        ff = self.conv(ln, self.dev(wf, F16), (b, h, w_, 4 * c), bias=self.dev(bf.float()), taps=1,
+                       pad=0, flags=L.EPI_GEGLU)
+        self.pool.put(ln)
+        h4 = self.conv(ff, self.w(tb + ".ff.net.2.weight"), shp, bias=self.f(tb + ".ff.net.2.bias"),
+                       residual=h3, taps=1, pad=0)
+        self.pool.put(ff, h3)
+        out = self.conv(h4, self.w(site + ".proj_out.weight"), shp, bias=self.f(site + ".proj_out.bias"),
+                        residual=x, taps=1, pad=0)
+        self.pool.put(h4)
+        return out
+
+    def _xattn(self, site, q, out):
+        mode = L.XATTN_SPLIT if self.gates_mode else L.XATTN_BASELINE
+        kv = self.kv[site][self.kv_slot]
+        self.be.tri_xattn(q, kv.view(self.B, self.T, -1), out, self.gates[site], self.lam, mode, HEADS)
+
+    def _emit_eps(self, x, w, bias):
+        self.be.conv_cout4(x, w, bias, self.eps_out[self.kv_slot], 0)
+
+    def _build(self):
+        b, s = self.B, self.S
+        x8 = self.pool.get((b, s, s, 8))
+        self.rec(self.be.pack_latents, self.lat_in, x8)
+        h = self.pool.get((b, s, s, 320))
+        self.rec(self.be.conv_cin8, x8, self.w("conv_in.weight", pack_conv_cin8), self.f("conv_in.bias"), h)
+        skips = [h]
+        for i in range(4):
+            for j in range(2):
+                hn = self._resnet(f"down_blocks.{i}.resnets.{j}", h)
+                if h is not skips[-1]:
+                    self.pool.put(h)
+                h = hn
+                if i < 3:
+                    hn = self._transformer(f"down_blocks.{i}.attentions.{j}", h)
+                    self.pool.put(h)
+                    h = hn
+                skips.append(h)
+            if i < 3:
+                c = h.shape[-1]
+                h = self.conv(h, self.w(f"down_blocks.{i}.downsamplers.0.conv.weight"),
+                              (b, h.shape[1] // 2, h.shape[2] // 2, c),
+                              bias=self.f(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=1)
+                skips.append(h)
+        hn = self._resnet("mid_block.resnets.0", h)        # h is skips[-1]: keep
+        h = hn
+        hn = self._transformer("mid_block.attentions.0", h)
+        self.pool.put(h)
+        h = self._resnet("mid_block.resnets.1", hn)
+        self.pool.put(hn)
+        for i in range(4):
+            for j in range(3):
+                skip = skips.pop()
+                hn = self._resnet(f"up_blocks.{i}.resnets.{j}", h, skip)
+                self.pool.put(h, skip)
+                h = hn
+                if i > 0:
+                    hn = self._transformer(f"up_blocks.{i}.attentions.{j}", h)
+                    self.pool.put(h)
+                    h = hn
+            if i < 3:
+                c = h.shape[-1]
+                hn = self.conv(h, self.w(f"up_blocks.{i}.upsamplers.0.conv.weight"),
+                               (b, h.shape[1] * 2, h.shape[2] * 2, c),
+                               bias=self.f(f"up_blocks.{i}.upsamplers.0.conv.bias"), ups=1, pad=1)
+                self.pool.put(h)
+                h = hn
+        g = self.gn(h, None, self.f("conv_norm_out.weight"), self.f("conv_norm_out.bias"), 1e-5, 1)
+        self.rec(self._emit_eps, g, self.w("conv_out.weight", pack_conv_cout4), self.f("conv_out.bias"))
+        self.pool.put(h, g)
+
+    # -- step-invariant preparation ----------------------------------------------------------------
+    def set_cond(self, cond: torch.Tensor, slot: int = 0):
+        """Project the conditioning tokens through to_k/to_v(/to_k_dis/to_v_dis) of all 16 sites."""
+        if cond.dim() == 2:
+            cond = cond.unsqueeze(1)
+        if cond.dim() != 3:
+            raise ValueError(f"cond_embed must have shape (B, D) or (B, seq_len, D), got {tuple(cond.shape)}")
+        if cond.shape[0] != self.B or cond.shape[1] != self.T or cond.shape[2] != 768:
+            raise ValueError(f"cond_embed must be ({self.B}, {self.T}, 768) for this plan, got {tuple(cond.shape)}")
+        self.be.copy_(self.cond16, cond)
+        for site, _ in self.sites:
+            self.be.igemm(self.cond16, self.kv_w[site], self.kv[site][slot], taps=1, pad=0)
+
+    def time_rows(self, t: torch.Tensor, out: torch.Tensor):
+        """rows[m] = cat_r time_emb_proj_r(SiLU(MLP(sinusoid(t[m]))))  for a vector of timesteps."""
+        m = t.shape[0]
+        feat = self.be.empty((m, 320), F32)
+        t1 = self.be.empty((m, 1280), F32)
+        t2 = self.be.empty((m, 1280), F32)
+        self.be.timestep_features(t, feat)
+        self.be.linear_rows(feat, self.w_t1, self.b_t1, t1, 0, 1)      # Linear -> SiLU
+        self.be.linear_rows(t1, self.w_t2, self.b_t2, t2, 0, 0)        # Linear  (= temb)
+        self.be.linear_rows(t2, self.w_tp, self.b_tp, out, 1, 0)       # SiLU -> 22 x Linear
+        return t2
+
+    def run_slot(self, slot: int, lam: float):
+        self.kv_slot, self.lam = slot, lam
+        self.run()
+
+    def forward(self, latents: torch.Tensor, t: torch.Tensor, cond: Optional[torch.Tensor],
+                lam: float = 0.0) -> torch.Tensor:
+        """General ``module(latents, t, cond)`` call: eps for arbitrary per-sample timesteps.
+        ``cond=None`` reuses the projections of the previous ``set_cond``."""
+        if tuple(latents.shape) != tuple(self.lat_in.shape):
+            raise ValueError(f"latents must be {tuple(self.lat_in.shape)}, got {tuple(latents.shape)}")
+        if t.dim() == 0:
+            t = t[None]
+        t = t.reshape(-1).long()
+        if t.shape[0] == 1:
+            t = t.expand(self.B)
+        if t.shape[0] != self.B:
+            raise ValueError(f"timesteps must have {self.B} entries, got {t.shape[0]}")
+        if cond is not None:
+            self.set_cond(cond, 0)
+        self.time_rows(self.be.to_device(t.contiguous()), self.temb_rows)
+        self.be.copy_(self.lat_in, latents.float())
+        self.run_slot(0, lam)
+        return self.be.clone(self.eps_out[0])
+
+
+# ----------------------------------------------------------------------------- VAE decoder
+class VaeDecoderPlan(_Plan):
+    def __init__(self, be, sd, batch: int, side: int, *, prefix="vae.vae", latent_scale=0.18215):
+        super().__init__(be)
+        self.B, self.S = batch, side
+        self.sd, self.prefix = sd, prefix + "."
+        self.gn_ws = be.empty((batch * L.GN_MAX_CHUNKS * GROUPS * 2,), F32)
+        self.z_in = be.zeros((batch, 4, side, side), F32)
+        self.img_out = be.zeros((batch, 3, side * 8, side * 8), F32)
+        self.inv_scale = 1.0 / latent_scale
+        self._build()
+
+    def w(self, key, pack=pack_conv):
+        return self.dev(pack(self.sd[self.prefix + key]))
+
+    def f(self, key):
+        return self.dev(self.sd[self.prefix + key].float())
+
+    def _res(self, name, x):
+        b, h, w_, cin = x.shape
+        cout = self.sd[self.prefix + name + ".conv1.weight"].shape[0]
+        g1 = self.gn(x, None, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-6, 1)
+        h1 = self.conv(g1, self.w(name + ".conv1.weight"), (b, h, w_, cout), bias=self.f(name + ".conv1.bias"))
+        self.pool.put(g1)
+        g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-6, 1)
+        self.pool.put(h1)
+        res = x
+        if cin != cout:
+            res = self.conv(x, self.w(name + ".conv_shortcut.weight"), (b, h, w_, cout),
+                            bias=self.f(name + ".conv_shortcut.bias"), taps=1, pad=0)
+        out = self.conv(g2, self.w(name + ".conv2.weight"), (b, h, w_, cout),
+                        bias=self.f(name + ".conv2.bias"), residual=res)
+        self.pool.put(g2)
+        if res is not x:
+            self.pool.put(res)
+        return out
+
+    def _attn(self, name, x):
+        b, h, w_, c = x.shape
+        g = self.gn(x, None, self.f(name + ".group_norm.weight"), self.f(name + ".group_norm.bias"), 1e-6, 0)
+        wqkv = self.dev(torch.cat([self.sd[self.prefix + name + f".to_{n}.weight"] for n in "qkv"]), F16)
+        bqkv = self.dev(torch.cat([self.sd[self.prefix + name + f".to_{n}.bias"] for n in "qkv"]).float())
+        qkv = self.conv(g, wqkv, (b, h, w_, 3 * c), bias=bqkv, taps=1, pad=0)
+        self.pool.put(g)
+        att = self.pool.get((b, h, w_, c))
+        self.rec(self.be.self_attn, qkv.view(b, h * w_, 3 * c), att.view(b, h * w_, c), 1)
+        self.pool.put(qkv)
+        out = self.conv(att, self.w(name + ".to_out.0.weight"), (b, h, w_, c),
+                        bias=self.f(name + ".to_out.0.bias"), residual=x, taps=1, pad=0)
+        self.pool.put(att)
+        return out
+
+    def _build(self):
+        b, s = self.B, self.S
+        d = "decoder."
+        z8 = self.pool.get((b, s, s, 8))
+        pq_w = self.dev(self.sd[self.prefix + "post_quant_conv.weight"].reshape(4, 4).float())
+        pq_b = self.f("post_quant_conv.bias")
+        self.rec(self.be.pack_latents, self.z_in, z8, self.inv_scale, pq_w, pq_b)
+        h = self.pool.get((b, s, s, 512))
+        self.rec(self.be.conv_cin8, z8, self.w(d + "conv_in.weight", pack_conv_cin8), self.f(d + "conv_in.bias"), h)
+        for blk in (lambda x: self._res(d + "mid_block.resnets.0", x),
+                    lambda x: self._attn(d + "mid_block.attentions.0", x),
+                    lambda x: self._res(d + "mid_block.resnets.1", x)):
+            hn = blk(h)
+            self.pool.put(h)
+            h = hn
+        for i in range(4):
+            for j in range(3):
+                hn = self._res(d + f"up_blocks.{i}.resnets.{j}", h)
+                self.pool.put(h)
+                h = hn
+            if i < 3:
+                c = h.shape[-1]
+                hn = self.conv(h, self.w(d + f"up_blocks.{i}.upsamplers.0.conv.weight"),
+                               (b, h.shape[1] * 2, h.shape[2] * 2, c),
+                               bias=self.f(d + f"up_blocks.{i}.upsamplers.0.conv.bias"), ups=1, pad=1)
+                self.pool.put(h)
+                h = hn
+        g = self.gn(h, None, self.f(d + "conv_norm_out.weight"), self.f(d + "conv_norm_out.bias"), 1e-6, 1)
+        self.rec(self.be.conv_cout4, g, self.w(d + "conv_out.weight", pack_conv_cout4),
+                 self.f(d + "conv_out.bias"), self.img_out, 1)
+        self.pool.put(h, g)
+
+
+# ----------------------------------------------------------------------------- DDIM loop
+class DdimLoop:
+    """Deterministic (eta = 0) DDIM loop over a UNetPlan: ONE captured step graph, replayed."""
+
+    def __init__(self, unet: UNetPlan, max_steps: int = 1000):
+        self.u = unet
+        self.be = unet.be
+        self.step = self.be.zeros((1,), torch.int32)
+        self.cur_coef = self.be.zeros((4,), F32)
+        self.graphs: Dict[Tuple, object] = {}
+        self.cap = 0
+        self.table = None
+        self.coef = None
+        self.nsteps = 0
+        self._reserve(64)
+
+    def _reserve(self, n: int):
+        if n <= self.cap:
+            return
+        for g in self.graphs.values():       # captured graphs hold the old table addresses
+            self.be.graph_destroy(g)
+        self.graphs.clear()
+        self.cap = n
+        self.table = self.be.zeros((n, self.u.temb_cols), F32)
+        self.coef = self.be.zeros((n, 4), F32)
+
+    def prepare(self, timesteps: torch.Tensor, alphas_cumprod: torch.Tensor):
+        """Coefficient rows computed on the host in fp32 exactly as the reference does per step
+        (inference_pipeline_ip.py:434-450), and the time-embedding rows of every step."""
+        ts = timesteps.detach().cpu().long()
+        n = ts.shape[0]
+        self._reserve(n)
+        ac = alphas_cumprod.detach().cpu().float()
+        coef = torch.empty(n, 4, dtype=F32)
+        for i in range(n):
+            a_t = ac[int(ts[i])]
+            coef[i, 0], coef[i, 1] = torch.sqrt(a_t), torch.sqrt(1.0 - a_t)
+            if i == n - 1:
+                coef[i, 2], coef[i, 3] = -1.0, 0.0          # last step returns x0 (:441-443)
+            else:
+                a_p = ac[int(ts[i + 1])]
+                coef[i, 2], coef[i, 3] = torch.sqrt(a_p), torch.sqrt(1.0 - a_p)
+        self.be.copy_(self.coef[:n], self.be.to_device(coef))
+        self.u.time_rows(self.be.to_device(ts), self.table[:n])
+        self.nsteps = n
+
+    def _one_step(self, lam: float, do_cfg: bool, guidance: float):
+        u = self.u
+        self.be.begin_step(self.table, u.temb_rows, self.coef, self.cur_coef, self.step)
+        u.run_slot(0, lam)
+        if do_cfg:
+            u.run_slot(1, lam)
+        self.be.ddim_update(u.lat_in, u.eps_out[0], u.eps_out[1] if do_cfg else None, guidance,
+                            self.cur_coef)
+
+    def run(self, lam: float, do_cfg: bool = False, guidance: float = 1.0, use_graph: bool = True,
+            trace: Optional[list] = None):
+        """Runs all prepared steps in place on ``unet.lat_in``."""
+        self.be.zero_(self.step)
+        if trace is not None or not use_graph:
+            for _ in range(self.nsteps):
+                self._one_step(lam, do_cfg, guidance)
+                if trace is not None:
+                    trace.append((self.be.clone(self.u.eps_out[0]), self.be.clone(self.u.lat_in)))
+            return
+        key = (float(lam), bool(do_cfg), float(guidance))
+        g = self.graphs.get(key)
+        if g is None:
+            self.be.synchronize()
+            self.be.graph_begin()
+            try:
+                self._one_step(lam, do_cfg, guidance)
+            finally:
+                g = self.be.graph_end()
+            self.graphs[key] = g
+        for _ in range(self.nsteps):
+            self.be.graph_launch(g)

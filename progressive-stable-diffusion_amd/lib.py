@@ -1,0 +1,111 @@
+"""ctypes binding of ``libdadd_hip.so`` (C ABI declared in ``include/dadd_hip.h``).
+
+There is no fallback: if the library is missing or a symbol is absent, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdadd_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ("igemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip")
+
+DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+XATTN_SPLIT, XATTN_BASELINE = 0, 1
+GN_MAX_CHUNKS = 64
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class IgemmDesc(C.Structure):
+    """Mirror of ``dadd_igemm_desc``."""
+    _fields_ = [(n, vp) for n in ("x", "x2", "w", "out", "partial", "bias", "rowvec", "residual")] + \
+               [(n, i32) for n in ("B", "Hi", "Wi", "C1", "C2", "Ho", "Wo", "N", "taps", "stride",
+                                   "ups", "pad", "ldo", "ldr", "ld_rowvec", "splitk", "flags",
+                                   "tile_n")]
+
+
+# name -> (restype, argtypes); every symbol include/dadd_hip.h declares
+PROTOTYPES = {
+    "dadd_last_error": (C.c_char_p, []),
+    "dadd_version": (C.c_int, []),
+    "dadd_init": (C.c_int, []),
+    "dadd_device_info": (C.c_int, [C.c_int, C.POINTER(i64)]),
+    "dadd_conv_igemm_f16": (C.c_int, [C.POINTER(IgemmDesc), vp]),
+    "dadd_conv3x3_cin8_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_conv3x3_cout4_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, vp]),
+    "dadd_pack_nchw_f32_to_nhwc8_f16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp,
+                                                  vp, vp]),
+    "dadd_groupnorm_f16": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
+                                     C.c_int, f32, C.c_int, vp]),
+    "dadd_layernorm_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
+    "dadd_self_attn_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, vp]),
+    "dadd_tri_xattn_f16": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, vp]),
+    "dadd_timestep_features_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "dadd_linear_rows_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_begin_step": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "dadd_ddim_update_f32": (C.c_int, [vp, vp, vp, f32, vp, i64, vp]),
+    "dadd_graph_begin": (C.c_int, [vp]),
+    "dadd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "dadd_graph_launch": (C.c_int, [vp, vp]),
+    "dadd_graph_destroy": (C.c_int, [vp]),
+    "dadd_prof_begin": (C.c_int, [C.c_int]),
+    "dadd_prof_end": (C.c_int, [C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into ``libdadd_hip.so`` (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "dadd_common.h"),
+                   os.path.join(os.path.dirname(_HERE), "include", "dadd_hip.h")]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *srcs, "-o",
+           LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every prototype; raises RuntimeError when it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is required (run __graft_entry__.build()); "
+            "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libdadd_hip.so does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map a status code to the exception the reference would raise for the same condition."""
+    if rc == DADD_OK:
+        return
+    msg = (_lib.dadd_last_error() or b"").decode() if _lib is not None else ""
+    if rc == DADD_EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(f"libdadd_hip error {rc}: {msg}")

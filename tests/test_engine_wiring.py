@@ -1,0 +1,181 @@
+"""CPU checks of the HOST logic: the engine's plans (op order, buffer reuse, weight packing, GEGLU
+row interleave, skip-concat order, split-K bookkeeping, time-row tables, DDIM coefficient table,
+module/pipeline protocol) executed through the TEST-ONLY torch backend and compared with the
+oracle.  No HIP kernel runs here; the same comparisons run on the GPU in test_gpu_parity.py.
+"""
+import pytest
+import torch
+
+from oracle import sampler as OS
+from oracle.sd_unet import unet_forward
+from oracle.sd_vae import vae_decode
+from progressive_stable_diffusion_amd import engine as E
+from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+from progressive_stable_diffusion_amd import weights as W
+from progressive_stable_diffusion_amd.config import default_config
+from progressive_stable_diffusion_amd.diffusion_module_ip import DiffusionModuleWithIP
+from tests.torch_backend import TorchRefBackend
+
+GATES = {"anatomy": (0.1, 0.9), "disease": (0.9, 0.1), "both": (0.5, 0.5)}
+TINY_CLIP = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                 image_size=224, patch_size=14, projection_dim=32)
+
+
+@pytest.fixture(scope="module")
+def full_sd():
+    """One seeded state dict for every test of this file (UNet incl. processors, VAE decoder,
+    conditioning modules sized for the tiny CLIP tower); baseline mode ignores the extra keys."""
+    shapes = dict(W.unet_shapes())
+    shapes.update(W.vae_shapes(encoder=False))
+    shapes.update(W.conditioning_shapes(clip_hidden=TINY_CLIP["hidden_size"],
+                                        clip_proj=TINY_CLIP["projection_dim"]))
+    return W.init_state_dict(shapes, 0, gates=GATES, warm_start_dis=False)
+
+
+@pytest.fixture(scope="module")
+def unet_sd(full_sd):
+    return full_sd
+
+
+def test_geglu_interleave_roundtrip():
+    w = torch.arange(512 * 3, dtype=torch.float32).reshape(512, 3)
+    b = torch.arange(512, dtype=torch.float32)
+    wp, bp = E.geglu_interleave(w, b)
+    # tile 0, wave 0: rows 0..31 are hidden columns 0..31, rows 32..63 the matching gates
+    assert bp[:32].tolist() == list(range(32))
+    assert bp[32:64].tolist() == list(range(256, 288))
+    assert bp[64:96].tolist() == list(range(32, 64))
+    assert sorted(bp.tolist()) == list(range(512))
+    assert torch.equal(wp[:, 0] / 3, bp)
+
+
+def test_splitk_heuristic():
+    assert E.choose_splitk(16384, 320, 2880, 160) == 1        # 64x64 level fills the chip
+    assert E.choose_splitk(256, 1280, 11520, 160) >= 8        # 8x8 level needs K splits
+    assert E.choose_splitk(64, 1280, 768, 160) <= 3
+    for m, n, k in ((256, 1280, 23040), (1024, 640, 5760), (4096, 640, 5760)):
+        s = E.choose_splitk(m, n, k, 160)
+        assert 1 <= s <= 32 and (k // 64) // s >= 4
+
+
+@pytest.mark.parametrize("lam", [0.0, 3.0])
+def test_unet_plan_matches_oracle(unet_sd, lam):
+    torch.manual_seed(1)
+    b, s = 2, 8
+    plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    x, cond = torch.randn(b, 4, s, s), torch.randn(b, 48, 768) * 0.5
+    t = torch.tensor([999, 333])
+    with torch.no_grad():
+        ref = unet_forward(unet_sd, x, t, cond, delta_scale=lam)
+        got = plan.forward(x, t, cond, lam=lam)
+    assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item())
+    # every pooled buffer is handed back exactly once: no leak of plan-time buffers
+    assert len(plan.ops) > 300
+
+
+def test_unet_plan_baseline_mode(full_sd):
+    torch.manual_seed(2)
+    sd = full_sd
+    b, s = 1, 8
+    plan = E.UNetPlan(TorchRefBackend(), sd, b, s, use_routing_gates=False)
+    x, cond = torch.randn(b, 4, s, s), torch.randn(b, 32, 768) * 0.5
+    t = torch.tensor([500])
+    with torch.no_grad():
+        ref = unet_forward(sd, x, t, cond, use_routing_gates=False)
+        got = plan.forward(x, t, cond)
+    assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item())
+    with pytest.raises(ValueError):
+        plan.set_cond(torch.zeros(b, 48, 768))        # wrong token count for this mode
+    with pytest.raises(ValueError):
+        plan.set_cond(torch.zeros(b, 2, 3, 768))      # unet.py:129-131
+
+
+def test_vae_decoder_plan_matches_oracle(full_sd):
+    torch.manual_seed(3)
+    sd = full_sd
+    b, s = 1, 8
+    plan = E.VaeDecoderPlan(TorchRefBackend(), sd, b, s, latent_scale=0.18215)
+    z = torch.randn(b, 4, s, s) * 0.18215
+    with torch.no_grad():
+        ref = ((vae_decode(sd, z / 0.18215).clamp(-1, 1) + 1) / 2).clamp(0, 1)
+    plan.z_in.copy_(z)
+    plan.run()
+    assert plan.img_out.shape == (b, 3, 8 * s, 8 * s)
+    assert (ref - plan.img_out).abs().max().item() < 1e-2
+
+
+def _module(cfg, sd, seed=0):
+    return DiffusionModuleWithIP(cfg, state_dict=sd, device="cpu", seed=seed, batch_size=2,
+                                 clip_config=TINY_CLIP, backend=TorchRefBackend())
+
+
+def _oracle_cfg(mod):
+    dc = mod.diff_cfg
+    return OS.OracleCfg(image_size=mod.cfg.dataset.image_size, use_routing_gates=dc.use_routing_gates,
+                        use_image_projection_plus=dc.use_image_projection_plus,
+                        use_feature_purifier=dc.use_feature_purifier)
+
+
+@pytest.mark.parametrize("gates_on", [True, False])
+def test_sampler_matches_oracle_config1_shape(gates_on, full_sd):
+    """BASELINE config 1 in miniature (64x64 image, 4 DDIM steps): variant (i) gates on with
+    steer lambda = 3.0, variant (ii) gates off with CFG g = 3.0 (two UNet calls per step)."""
+    cfg = default_config(**{"dataset.image_size": 64, "model.use_routing_gates": gates_on})
+    mod = _module(cfg, full_sd)
+    torch.manual_seed(5)
+    target = torch.tensor([3.0, 1.25])
+    source = torch.tensor([0.0, 2.0])
+    pix = torch.randn(1, 3, 224, 224)
+    lat = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(1234))
+    kw = dict(steer_scale=3.0) if gates_on else dict(guidance_scale=3.0)
+    trace = []
+    with torch.no_grad():
+        got = PIPE._ddim_sample_ip(mod, target, source, pix, 4, torch.device("cpu"), latents=lat,
+                                   use_graph=False, trace=trace, **kw)
+        feats = mod.image_encoder.get_hidden_states(pix)
+        ref_trace = []
+        ref = OS.ddim_sample(mod._sd, _oracle_cfg(mod), target, source, feats, 4, lat,
+                             trace=ref_trace, **kw)
+        # conditioning tokens: fp32 on both sides
+        c_ref = OS.prepare_conditioning(mod._sd, _oracle_cfg(mod), target, source, feats)
+        c_got = PIPE._prepare_conditioning(mod, target, source, pix)
+    assert (c_ref - c_got).abs().max().item() < 1e-4
+    assert len(trace) == 4
+    for (e_g, x_g), (e_r, x_r) in zip(trace, ref_trace):
+        if gates_on:   # with CFG the trace holds the conditional branch only
+            assert (e_g - e_r).abs().max().item() < 2e-2
+        # x0 = (x - s1*eps)/s0 amplifies an eps error by 1/sqrt(abar_999) = 25x at the first step,
+        # and CFG by another (1 + 2g): fp16-storage noise, not a wiring difference
+        assert (x_g - x_r).abs().max().item() < (5e-2 if gates_on else 0.2)
+    assert (got - ref).abs().max().item() < (5e-2 if gates_on else 0.2)
+    with torch.no_grad():
+        img = PIPE._latents_to_images(mod, got)
+        img_ref = OS.latents_to_images(mod._sd, _oracle_cfg(mod), ref)
+    assert img.shape == (2, 3, 64, 64) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert (img - img_ref).abs().max().item() < (3e-2 if gates_on else 0.1)
+
+
+def test_module_protocol_and_errors(full_sd):
+    cfg = default_config(**{"dataset.image_size": 64})
+    mod = _module(cfg, full_sd)
+    assert mod.diff_cfg.latent_scale == 0.18215 and mod.diff_cfg.num_train_timesteps == 1000
+    assert mod.alphas_cumprod[999].item() == pytest.approx(0.001578963, rel=2e-6)
+    procs = [m for _, m in mod.unet.unet.named_modules() if hasattr(m.processor, "delta_scale")]
+    assert len(procs) == 16
+    PIPE._set_delta_scale_on_processors(mod, 0.7)
+    assert mod.unet.unet.delta_scale() == 0.7
+    roles = {n.split(".transformer")[0]: p.processor.block_type for n, p in mod.unet.unet.named_modules()}
+    assert roles["mid_block.attentions.0"] == "disease" and roles["down_blocks.0.attentions.0"] == "anatomy"
+    with pytest.raises(ValueError):
+        PIPE._ddim_sample_ip(mod, torch.zeros(2), torch.zeros(2), torch.zeros(1, 3, 224, 224), 1001,
+                             torch.device("cpu"))
+    with pytest.raises(ValueError):
+        PIPE._build_labels(0)
+    assert PIPE._build_labels(13).tolist()[1] == 0.25
+    with pytest.raises(FileNotFoundError):
+        PIPE._load_config("/nonexistent/train_ip.yaml")
+    bad = default_config(**{"diffusion.noise_schedule": "cosine"})
+    with pytest.raises(NotImplementedError):
+        _module(bad, full_sd)
+    with pytest.raises(ValueError):
+        mod(torch.zeros(2, 4, 8, 8), torch.zeros(2, dtype=torch.long), torch.zeros(2, 3, 4, 768))

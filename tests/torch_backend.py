@@ -1,0 +1,187 @@
+"""TEST-ONLY operator backend: the op contract of ``progressive_stable_diffusion_amd.backend``
+restated with plain torch on the CPU (fp16 storage, fp32 arithmetic).
+
+Purpose: (1) let the CPU suite check the *wiring* of the engine's plans (which buffer feeds which
+op, weight packing, GEGLU interleave, skip order, split-K bookkeeping) against the oracle without
+a GPU; (2) serve as the per-op torch reference the ``-m gpu`` kernel tests compare the HIP kernels
+with.  The product never imports this module and has no CPU path.
+"""
+from __future__ import annotations
+
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+
+
+def geglu_deinterleave_index(n: int) -> torch.Tensor:
+    """Inverse of engine.geglu_interleave: physical row -> logical row."""
+    n2 = n // 2
+    idx = torch.arange(n)
+    tile, r = idx // 128, idx % 128
+    wn, rr = r // 64, r % 64
+    col = tile * 64 + wn * 32 + (rr % 32)
+    return torch.where(rr < 32, col, n2 + col)
+
+
+class TorchRefBackend:
+    name = "torch-ref"
+
+    def __init__(self, device="cpu"):
+        self.device = torch.device(device)
+        self.launches = 0
+
+    # plumbing -------------------------------------------------------------------------------
+    def ctx(self):
+        return contextlib.nullcontext()
+
+    def empty(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    zeros = empty
+
+    def to_device(self, t, dtype=None):
+        return t.to(device=self.device, dtype=dtype or t.dtype).contiguous()
+
+    def copy_(self, dst, src):
+        dst.copy_(src.reshape(dst.shape))
+
+    def zero_(self, t):
+        t.zero_()
+
+    def clone(self, t):
+        return t.detach().clone()
+
+    def synchronize(self):
+        pass
+
+    def wait_current(self):
+        pass
+
+    def release_to_current(self):
+        pass
+
+    # ops ------------------------------------------------------------------------------------
+    def pack_latents(self, x, out, scale=1.0, mat=None, vec=None):
+        v = x.float() * scale
+        if mat is not None:
+            v = torch.einsum("oc,bchw->bohw", mat.float(), v)
+            if vec is not None:
+                v = v + vec.float()[None, :, None, None]
+        out.zero_()
+        out[..., : x.shape[1]] = v.permute(0, 2, 3, 1).to(out.dtype)
+
+    def conv_cin8(self, x, w, bias, out):
+        co = w.shape[0]
+        wt = w.float().reshape(co, 3, 3, 8).permute(0, 3, 1, 2)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, None if bias is None else bias.float(), padding=1)
+        out.copy_(y.permute(0, 2, 3, 1).to(out.dtype))
+
+    def conv_cout4(self, x, w, bias, out, mode=0):
+        co, _, c = w.shape
+        wt = w.float().reshape(co, 3, 3, c).permute(0, 3, 1, 2)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, None if bias is None else bias.float(), padding=1)
+        if mode == 1:
+            y = ((y.clamp(-1, 1) + 1.0) / 2.0).clamp(0, 1)
+        out.copy_(y)
+
+    def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
+              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0):
+        self.launches += 1
+        xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
+        b, hi, wi, cin = xin.shape
+        n = w.shape[0]
+        assert cin % 64 == 0 and x.shape[-1] % 64 == 0 and n % 8 == 0
+        assert w.shape[1] == taps * cin
+        ho, wo = out.shape[1], out.shape[2]
+        xn = xin.permute(0, 3, 1, 2)
+        if ups:
+            xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+        k = 3 if taps == 9 else 1
+        wt = w.float().reshape(n, k, k, cin).permute(0, 3, 1, 2)
+        if pad == 0 and k == 3:       # asymmetric (0,1,0,1) padding of the VAE-encoder downsample
+            xn = F.pad(xn, (0, 2, 0, 2))
+            y = F.conv2d(xn, wt, None, stride=stride)[:, :, :ho, :wo]
+        else:
+            y = F.conv2d(xn, wt, None, stride=stride, padding=pad)
+        assert y.shape[2] == ho and y.shape[3] == wo, (y.shape, out.shape)
+        y = y.permute(0, 2, 3, 1)
+        if flags & EPI_BIAS:
+            y = y + bias.float()
+        if flags & EPI_ROWVEC:
+            y = y + rowvec.float()[:, None, None, :]
+        if flags & EPI_GEGLU:
+            y = y[..., geglu_deinterleave_index(n).argsort()]   # undo the physical row order
+            hid, gate = y.chunk(2, dim=-1)
+            y = hid * F.gelu(gate)
+        if flags & EPI_RESIDUAL:
+            y = y + residual.float()
+        out.copy_(y.to(out.dtype))
+
+    def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu):
+        x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
+        y = F.group_norm(x.permute(0, 3, 1, 2), groups, gamma.float(), beta.float(), eps)
+        if silu:
+            y = F.silu(y)
+        out.copy_(y.permute(0, 2, 3, 1).to(out.dtype))
+
+    def layernorm(self, x, gamma, beta, out, eps=1e-5):
+        out.copy_(F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps).to(out.dtype))
+
+    def self_attn(self, qkv, out, heads):
+        b, n, c3 = qkv.shape
+        c = c3 // 3
+        d = c // heads
+        q, k, v = (t.float().view(b, n, heads, d).transpose(1, 2) for t in qkv.split(c, dim=-1))
+        p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
+        out.copy_((p @ v).transpose(1, 2).reshape(b, n, c).to(out.dtype))
+
+    def tri_xattn(self, q, kv, out, gates, lam, mode, heads):
+        b, n, c = q.shape
+        d = c // heads
+        qh = q.float().view(b, n, heads, d).transpose(1, 2)
+
+        def path(tok0, ntok, kcol, vcol):
+            k = kv[:, tok0:tok0 + ntok, kcol:kcol + c].float().view(b, ntok, heads, d).transpose(1, 2)
+            v = kv[:, tok0:tok0 + ntok, vcol:vcol + c].float().view(b, ntok, heads, d).transpose(1, 2)
+            return torch.softmax(qh @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v
+
+        if mode == 0:
+            z = gates[0].float() * path(16, 16, 0, c) + gates[1].float() * path(0, 16, 2 * c, 3 * c)
+            if lam != 0.0:
+                z = z + lam * path(32, 16, 2 * c, 3 * c)
+        else:
+            z = path(0, 32, 0, c)
+        out.copy_(z.transpose(1, 2).reshape(b, n, c).to(out.dtype))
+
+    def timestep_features(self, t, out):
+        half = out.shape[1] // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        ang = t.float()[:, None] * freqs[None, :]
+        out.copy_(torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1))
+
+    def linear_rows(self, x, w, bias, out, act_in=0, act_out=0):
+        v = F.silu(x.float()) if act_in else x.float()
+        y = F.linear(v, w.float(), None if bias is None else bias.float())
+        out.copy_(F.silu(y) if act_out else y)
+
+    def begin_step(self, table, cur_rows, coef, cur_coef, step):
+        r = int(step.item())
+        cur_rows.copy_(table[r][None, :].expand_as(cur_rows))
+        cur_coef.copy_(coef[r])
+        step += 1
+
+    def ddim_update(self, x, eps_c, eps_u, guidance, coef):
+        e = eps_c if eps_u is None else eps_u + guidance * (eps_c - eps_u)
+        x0 = ((x - coef[1] * e) / coef[0]).clamp(-4.0, 4.0)
+        x.copy_(x0 if coef[2] < 0 else coef[2] * x0 + coef[3] * e)
+
+    # graphs: the reference backend just replays eagerly ---------------------------------------
+    def graph_begin(self):
+        self._cap = []
+
+    def graph_end(self):
+        raise NotImplementedError("the reference backend has no graphs; run with use_graph=False")
