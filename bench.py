@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec at 512x512, 50 DDIM steps, batch-per-GPU 4 (BASELINE.json).
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU:
+``_ddim_sample_ip`` (conditioning prep + 50 hipGraph-replayed UNet/DDIM steps, delta steering
+lambda = 3.0) + ``_latents_to_images`` (VAE decode), then — for N > 1 — the single RCCL all-gather of
+decoded frames.  Workload = BASELINE.json configs[1] per rank (weak scaling: 4 images per GPU).
+Weights are seeded random tensors of the SD-1.4 / DADD architecture (no checkpoints offline).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  ``roofline`` is measured live: after the timed region the same UNet
+step is launched eagerly with every implicit-GEMM launch bracketed by HIP events on its own stream
+(graph replays cannot carry per-kernel events); ``cpu_baseline`` times the CPU oracle (a port of the
+reference's CPU path) on a bounded sample on rank 0 at N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F16_TFLOPS = 2500.0           # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md chip table
+FLOP_PER_IMAGE = 42.56e12          # 50 x 800.8 GF + 2514.5 GF
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3, help="timed passes (each = 4 images x 50 DDIM steps + decode)")
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--image-size", type=int, default=512)
+    p.add_argument("--batch", type=int, default=4)
+    p.add_argument("--ddim-steps", type=int, default=50)
+    p.add_argument("--steer-scale", type=float, default=3.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--tiny-clip", action="store_true", help="2-layer CLIP tower (debug only)")
+    return p.parse_args()
+
+
+def cpu_baseline(sd, image_size):
+    """The oracle (CPU port of the reference path) on a bounded sample of the same workload:
+    1 UNet call at B=1 + 1 VAE decode, extrapolated linearly to 50 steps (stated as extrapolated)."""
+    from oracle.sd_unet import unet_forward
+    from oracle.sd_vae import vae_decode
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    s = image_size // 8
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, s, s, generator=g)
+    cond = torch.randn(1, 48, 768, generator=g) * 0.5
+    t = torch.tensor([500])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        unet_forward(sd, x, t, cond, delta_scale=3.0)
+        t_unet = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        vae_decode(sd, x)
+        t_dec = time.perf_counter() - t0
+    per_image = 50 * t_unet + t_dec
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 UNet eps call (B=1, {image_size}x{image_size}) = {t_unet:.2f}s and 1 VAE decode = "
+                      f"{t_dec:.2f}s on the CPU oracle (fp32 torch), extrapolated to 50 steps + decode"}
+
+
+def main():
+    a = parse()
+    from progressive_stable_diffusion_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    from progressive_stable_diffusion_amd import lib
+    from progressive_stable_diffusion_amd import weights as W
+    from progressive_stable_diffusion_amd.config import default_config
+    from progressive_stable_diffusion_amd.diffusion_module_ip import DiffusionModuleWithIP
+    if rank == 0:
+        lib.build()
+    D.barrier()
+
+    cfg = default_config(**{"dataset.image_size": a.image_size})
+    gates = {"anatomy": (0.1, 0.9), "disease": (0.9, 0.1), "both": (0.5, 0.5)}
+    tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                image_size=224, patch_size=14, projection_dim=32) if a.tiny_clip else None
+    shapes = dict(W.unet_shapes())
+    shapes.update(W.vae_shapes(encoder=False))
+    shapes.update(W.conditioning_shapes(clip_hidden=64 if tiny else 1024))
+    sd = W.init_state_dict(shapes, 0, gates=gates)
+    mod = DiffusionModuleWithIP(cfg, state_dict=sd, device=dev, seed=0, batch_size=a.batch, clip_config=tiny)
+
+    side = a.image_size // 8
+    n_total = a.batch * world                       # weak scaling: 4 labels per GPU
+    labels = torch.linspace(0.0, 3.0, n_total)
+    target, _ = D.shard_labels(labels, rank, world, a.batch)
+    target = target.to(dev)
+    source = torch.full_like(target, 2.0)
+    pix = (torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
+    lat = D.shared_initial_latent(1234, 4, side).repeat(a.batch, 1, 1, 1)
+
+    def one_pass():
+        with torch.no_grad():
+            z = PIPE._ddim_sample_ip(mod, target, source, pix, a.ddim_steps, dev,
+                                     steer_scale=a.steer_scale, latents=lat)
+            frames = PIPE._latents_to_images(mod, z)
+            return D.all_gather_frames(frames)
+
+    for _ in range(a.warmup):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        frames = one_pass()
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert frames.shape == (n_total, 3, a.image_size, a.image_size)
+
+    roof = None
+    if not a.no_roofline:
+        loop = mod.ddim_loop(a.batch, side)
+        be = loop.be
+        with torch.no_grad():    # same state as the timed passes: cond projected, tables prepared
+            be.copy_(loop.u.lat_in, lat.to(dev))
+            be.zero_(loop.step)
+            be.synchronize()
+            be.prof_begin(1)
+            for _ in range(2):
+                loop._one_step(a.steer_scale, False, 1.0)
+            st = be.prof_end()
+        if st["launches"] > 0 and st["ms"] > 0:
+            ach = st["flop"] / (st["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "igemm_kernel<128|160> (implicit-GEMM conv/linear)",
+                    "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
+                    "traffic": None, "launches": st["launches"],
+                    "avg_launch_us": st["ms"] * 1e3 / st["launches"],
+                    "flop_per_launch_avg": st["flop"] / st["launches"]}
+
+    if rank == 0:
+        images = n_total * a.steps
+        value = images / elapsed
+        out = {
+            "metric": "images/sec at 512x512, 50 DDIM steps, bs/GPU=4", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic (seeded random-init SD-1.4/DADD weights, CPU-seeded noise, random structure image)",
+            "config": {"workload": f"{a.image_size}x{a.image_size}, {a.ddim_steps} DDIM steps, bs={a.batch}/GPU, "
+                                   f"delta-steer lambda={a.steer_scale}, routing gates on, conditioning prep + "
+                                   "VAE decode included", "global_batch": n_total,
+                       "parallelism": f"batch-shard x{world} + 1 all-gather of frames"},
+            "achieved_tflops_whole_job": value * FLOP_PER_IMAGE / 1e12 if a.image_size == 512 else None,
+            "frac_of_mfma_peak_whole_job": (value * FLOP_PER_IMAGE / 1e12) / (PEAK_F16_TFLOPS * world)
+            if a.image_size == 512 else None,
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, a.image_size)
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

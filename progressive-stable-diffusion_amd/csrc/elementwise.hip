@@ -197,16 +197,23 @@ __global__ __launch_bounds__(1024) void begin_step_kernel(const float* __restric
 __global__ __launch_bounds__(256) void ddim_kernel(float* __restrict__ x, const float* __restrict__ ec,
                                                    const float* __restrict__ eu, float g,
                                                    const float* __restrict__ coef, int64_t n) {
+#pragma clang fp contract(off)  // __fmul_rn/__fsub_rn are plain * and - to the optimiser: forbid FMA fusion
   const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float e = ec[i];
     if (eu) {
       const float u = eu[i];
-      e = __fadd_rn(u, __fmul_rn(g, __fsub_rn(e, u)));
+      const float d = e - u;
+      const float gd = g * d;
+      e = u + gd;
     }
-    float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c1, e)), c0);
+    const float s = c1 * e;
+    const float num = x[i] - s;
+    float x0 = num / c0;
     x0 = fminf(fmaxf(x0, -4.0f), 4.0f);
-    x[i] = (c2 < 0.f) ? x0 : __fadd_rn(__fmul_rn(c2, x0), __fmul_rn(c3, e));
+    const float a = c2 * x0;
+    const float b = c3 * e;
+    x[i] = (c2 < 0.f) ? x0 : a + b;
   }
 }
 

@@ -1,0 +1,35 @@
+#!/usr/bin/env bash
+# One gpurun call = one box acquisition (minutes of budget): run the whole GPU checklist in it.
+# A step that TIMES OUT or is KILLED ends the call (no further GPU work on a possibly wedged card);
+# ordinary test failures are logged and the later steps still run.
+# usage: scripts/gpu_round.sh <tag> [steps...]   steps: kernels parity smoke bench prof pmc
+set -u
+tag=${1:-r01}; shift || true
+steps=${*:-"kernels parity smoke bench prof"}
+out=gpurun_out/$tag; mkdir -p "$out"
+run() {  # run <name> <timeout_s> <cmd...>
+  local name=$1 to=$2; shift 2
+  echo "=== [$name] $(date +%T) $*" | tee -a "$out/summary.txt"
+  timeout -k 10 "$to" "$@" > "$out/$name.log" 2>&1
+  local rc=$?
+  echo "=== [$name] rc=$rc" | tee -a "$out/summary.txt"
+  tail -n "${TAILN:-15}" "$out/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name timed out/killed: stopping" | tee -a "$out/summary.txt"; exit $rc; fi
+  return 0
+}
+python -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1 || { tail -20 "$out/build.log"; exit 1; }
+for s in $steps; do
+  case $s in
+    kernels) run kernels 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=300 ;;
+    parity)  run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 ;;
+    smoke)   run smoke 300 python __graft_entry__.py smoke ;;
+    bench)   run bench 900 python bench.py --steps 2 --warmup 1 ;;
+    prof)    export TMPDIR=/tmp
+             run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline
+             find "$out/prof" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} sh -c 'head -40 "{}" > '"$out"'/kernel_stats_top.csv'
+             find "$out/prof" -name "*kernel_trace*.csv" -size +20M -delete 2>/dev/null ;;
+    pmc)     export TMPDIR=/tmp
+             run pmc 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline ;;
+  esac
+done
+echo "=== done $(date +%T)" | tee -a "$out/summary.txt"

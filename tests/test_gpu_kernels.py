@@ -1,0 +1,298 @@
+"""-m gpu: every HIP kernel, called through the C ABI (ctypes), against the plain-torch fp32
+reference of the same op (tests/torch_backend.py) on identical seeded inputs.
+
+Tolerances (stated per test): operands are fp16, accumulation fp32; the reference computes in fp32
+from the same fp16 operands and rounds once to fp16, so the expected difference is one fp16
+rounding of the result (rel 2^-11 = 4.9e-4) plus accumulation-order noise.
+"""
+import math
+
+import pytest
+import torch
+
+from tests.torch_backend import TorchRefBackend
+
+pytestmark = pytest.mark.gpu
+
+F16, F32 = torch.float16, torch.float32
+REF = TorchRefBackend()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from progressive_stable_diffusion_amd.backend import HipBackend
+    return HipBackend(torch.device("cuda:0"))
+
+
+def rnd(shape, seed, scale=1.0, dtype=F16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def dev(hip, t):
+    return None if t is None else hip.to_device(t)
+
+
+def close(got, ref, atol, rtol, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} off, max err "
+                                 f"{err.max().item():.4e} at ref {ref.flatten()[err.argmax()].item():.4e}")
+
+
+def run_igemm(hip, x, w, out_shape, **kw):
+    tens = {k: kw.pop(k, None) for k in ("x2", "bias", "rowvec", "residual")}
+    splitk = kw.get("splitk", 1)
+    o_ref = torch.zeros(out_shape, dtype=F16)
+    REF.igemm(x, w, o_ref, **tens, **kw)
+    o = hip.zeros(out_shape, F16)
+    m = out_shape[0] * out_shape[1] * out_shape[2]
+    partial = hip.zeros((splitk * m * w.shape[0],), F32) if splitk > 1 else None
+    hip.igemm(dev(hip, x), dev(hip, w), o, **{k: dev(hip, v) for k, v in tens.items()},
+              partial=partial, **kw)
+    hip.synchronize()
+    return o, o_ref
+
+
+@pytest.mark.parametrize("m,n,k,tile", [(200, 320, 320, 0), (130, 256, 128, 128), (64, 1280, 768, 160),
+                                        (513, 960, 640, 0)])
+def test_igemm_linear(hip, m, n, k, tile):
+    x, w = rnd((1, m, 1, k), 1), rnd((n, k), 2, 1 / math.sqrt(k))
+    bias = rnd((n,), 3, 0.1, F32)
+    o, o_ref = run_igemm(hip, x, w, (1, m, 1, n), bias=bias, flags=1, tile_n=tile)
+    close(o, o_ref, 2e-3, 2e-3, f"linear {m}x{n}x{k}")
+
+
+@pytest.mark.parametrize("cin,cout,h,stride,ups,pad", [(320, 320, 16, 1, 0, 1), (128, 256, 12, 1, 0, 1),
+                                                       (320, 320, 16, 2, 0, 1), (640, 640, 8, 1, 1, 1),
+                                                       (128, 128, 16, 2, 0, 0)])
+def test_igemm_conv3x3(hip, cin, cout, h, stride, ups, pad):
+    b = 2
+    ho = h * 2 if ups else (h // 2 if stride == 2 else h)
+    x, w = rnd((b, h, h, cin), 4), rnd((cout, 9 * cin), 5, 1 / math.sqrt(9 * cin))
+    bias, rowvec = rnd((cout,), 6, 0.1, F32), rnd((b, cout), 7, 0.3, F32)
+    res = rnd((b, ho, ho, cout), 8)
+    o, o_ref = run_igemm(hip, x, w, (b, ho, ho, cout), bias=bias, rowvec=rowvec, residual=res, taps=9,
+                         stride=stride, ups=ups, pad=pad, flags=7)
+    close(o, o_ref, 3e-3, 2e-3, f"conv3x3 cin{cin} s{stride} u{ups} p{pad}")
+
+
+@pytest.mark.parametrize("taps", [1, 9])
+def test_igemm_skip_concat(hip, taps):
+    b, h, c1, c2, n = 2, 8, 640, 320, 640
+    x, x2 = rnd((b, h, h, c1), 9), rnd((b, h, h, c2), 10)
+    w = rnd((n, taps * (c1 + c2)), 11, 1 / math.sqrt(taps * (c1 + c2)))
+    bias = rnd((n,), 12, 0.1, F32)
+    o, o_ref = run_igemm(hip, x, w, (b, h, h, n), x2=x2, bias=bias, taps=taps, pad=taps // 9, flags=1)
+    close(o, o_ref, 3e-3, 2e-3, f"concat taps{taps}")
+
+
+@pytest.mark.parametrize("splitk", [2, 7, 16])
+def test_igemm_splitk_matches_single_pass(hip, splitk):
+    b, h, c, n = 1, 8, 1280, 1280
+    x, w = rnd((b, h, h, c), 13), rnd((n, 9 * c), 14, 1 / math.sqrt(9 * c))
+    bias, res = rnd((n,), 15, 0.1, F32), rnd((b, h, h, n), 16)
+    o, o_ref = run_igemm(hip, x, w, (b, h, h, n), bias=bias, residual=res, taps=9, pad=1, flags=5,
+                         splitk=splitk)
+    close(o, o_ref, 3e-3, 2e-3, f"splitk {splitk}")
+
+
+def test_igemm_geglu(hip):
+    from progressive_stable_diffusion_amd.engine import geglu_interleave
+    m, c = 300, 320
+    x = rnd((1, m, 1, c), 17)
+    w, bias = rnd((8 * c, c), 18, 1 / math.sqrt(c), F32), rnd((8 * c,), 19, 0.1, F32)
+    wp, bp = geglu_interleave(w, bias)
+    o, o_ref = run_igemm(hip, x, wp.to(F16), (1, m, 1, 4 * c), bias=bp, flags=1 | 8, tile_n=128)
+    close(o, o_ref, 3e-3, 3e-3, "geglu")
+    # and against the un-interleaved definition: hidden * gelu(gate)
+    y = torch.nn.functional.linear(x.float().reshape(m, c), w.to(F16).float(), bias)
+    hid, gate = y.chunk(2, dim=-1)
+    close(o.reshape(m, 4 * c), hid * torch.nn.functional.gelu(gate), 3e-3, 3e-3, "geglu vs definition")
+
+
+def test_igemm_rejects_bad_contract(hip):
+    x, w = rnd((1, 8, 1, 96), 20), rnd((64, 96), 21)
+    with pytest.raises(ValueError):
+        hip.igemm(dev(hip, x), dev(hip, w), hip.zeros((1, 8, 1, 64), F16))      # C % 64 != 0
+
+
+@pytest.mark.parametrize("c1,c2,hw,silu,eps", [(320, 0, 256, 1, 1e-5), (1280, 640, 64, 1, 1e-5),
+                                               (640, 320, 100, 0, 1e-6), (128, 0, 4096, 1, 1e-6),
+                                               (1280, 1280, 16, 1, 1e-5)])
+def test_groupnorm(hip, c1, c2, hw, silu, eps):
+    b, side = 2, int(math.isqrt(hw))
+    x1 = rnd((b, side, side, c1), 22, 1.5) + 0.3
+    x2 = (rnd((b, side, side, c2), 23, 0.7) - 0.2) if c2 else None
+    c = c1 + c2
+    gamma, beta = rnd((c,), 24, 0.2, F32) + 1.0, rnd((c,), 25, 0.2, F32)
+    o_ref = torch.zeros(b, side, side, c, dtype=F16)
+    REF.groupnorm(x1, x2, gamma, beta, o_ref, None, 32, eps, silu)
+    o = hip.zeros((b, side, side, c), F16)
+    ws = hip.zeros((b * 64 * 32 * 2,), F32)
+    hip.groupnorm(dev(hip, x1), dev(hip, x2), dev(hip, gamma), dev(hip, beta), o, ws, 32, eps, silu)
+    hip.synchronize()
+    close(o, o_ref, 3e-3, 2e-3, f"groupnorm c{c1}+{c2} hw{hw}")
+
+
+@pytest.mark.parametrize("m,c", [(100, 320), (37, 640), (64, 1280)])
+def test_layernorm(hip, m, c):
+    x = rnd((m, c), 26, 2.0) + 0.5
+    gamma, beta = rnd((c,), 27, 0.2, F32) + 1.0, rnd((c,), 28, 0.2, F32)
+    o_ref = torch.zeros(m, c, dtype=F16)
+    REF.layernorm(x, gamma, beta, o_ref)
+    o = hip.zeros((m, c), F16)
+    hip.layernorm(dev(hip, x), dev(hip, gamma), dev(hip, beta), o)
+    hip.synchronize()
+    close(o, o_ref, 2e-3, 2e-3, f"layernorm {m}x{c}")
+
+
+@pytest.mark.parametrize("heads,d,n", [(8, 40, 256), (8, 40, 144), (8, 80, 64), (8, 160, 100),
+                                       (8, 160, 16), (1, 512, 192), (8, 40, 1024)])
+def test_self_attention(hip, heads, d, n):
+    b, c = 2, heads * d
+    qkv = rnd((b, n, 3 * c), 29, 1.0)
+    qkv[0, n // 3, c:2 * c] *= 4.0          # a spiky key row: exercises the running-max rescale
+    o_ref = torch.zeros(b, n, c, dtype=F16)
+    REF.self_attn(qkv, o_ref, heads)
+    o = hip.zeros((b, n, c), F16)
+    hip.self_attn(dev(hip, qkv), o, heads)
+    hip.synchronize()
+    close(o, o_ref, 3e-3, 3e-3, f"self_attn h{heads} d{d} n{n}")
+
+
+@pytest.mark.parametrize("d", [40, 80, 160])
+@pytest.mark.parametrize("mode,lam", [(0, 0.0), (0, 3.0), (0, -0.5), (1, 0.0)])
+def test_tri_xattn(hip, d, mode, lam):
+    b, n, heads = 2, 300, 8
+    c = heads * d
+    t_tok, ld = (48, 4 * c) if mode == 0 else (32, 2 * c)
+    q, kv = rnd((b, n, c), 30, 1.0), rnd((b, t_tok, ld), 31, 1.0)
+    gates = torch.tensor([0.1, 0.9])
+    o_ref = torch.zeros(b, n, c, dtype=F16)
+    REF.tri_xattn(q, kv, o_ref, gates, lam, mode, heads)
+    o = hip.zeros((b, n, c), F16)
+    hip.tri_xattn(dev(hip, q), dev(hip, kv), o, dev(hip, gates) if mode == 0 else None, lam, mode, heads)
+    hip.synchronize()
+    close(o, o_ref, 4e-3, 4e-3, f"tri_xattn d{d} mode{mode} lam{lam}")
+
+
+def test_tri_xattn_lambda_zero_equals_two_pathways(hip):
+    """routing_gates.py:160,177-178: delta_scale == 0 must skip the delta pathway exactly; garbage
+    (even NaN) in the delta tokens must not leak."""
+    b, n, heads, d = 1, 64, 8, 40
+    c = heads * d
+    q, kv = rnd((b, n, c), 32), rnd((b, 48, 4 * c), 33)
+    kv2 = kv.clone()
+    kv2[:, 32:] = float("nan")
+    g = dev(hip, torch.tensor([0.9, 0.1]))
+    o1, o2 = hip.zeros((b, n, c), F16), hip.zeros((b, n, c), F16)
+    hip.tri_xattn(dev(hip, q), dev(hip, kv), o1, g, 0.0, 0, heads)
+    hip.tri_xattn(dev(hip, q), dev(hip, kv2), o2, g, 0.0, 0, heads)
+    hip.synchronize()
+    assert torch.equal(o1.cpu(), o2.cpu())
+
+
+def test_thin_convs_and_pack(hip):
+    b, s = 2, 16
+    lat = rnd((b, 4, s, s), 34, 1.0, F32)
+    mat, vec = rnd((4, 4), 35, 0.5, F32), rnd((4,), 36, 0.1, F32)
+    for m, v, sc in ((None, None, 1.0), (mat, vec, 1.0 / 0.18215)):
+        o_ref = torch.zeros(b, s, s, 8, dtype=F16)
+        REF.pack_latents(lat, o_ref, sc, m, v)
+        o = hip.zeros((b, s, s, 8), F16)
+        hip.pack_latents(dev(hip, lat), o, sc, dev(hip, m), dev(hip, v))
+        hip.synchronize()
+        close(o, o_ref, 2e-3, 2e-3, "pack")
+    x8 = o_ref
+    w = rnd((320, 9, 8), 37, 0.2)
+    w[:, :, 4:] = 0
+    bias = rnd((320,), 38, 0.1, F32)
+    o_ref = torch.zeros(b, s, s, 320, dtype=F16)
+    REF.conv_cin8(x8, w, bias, o_ref)
+    o = hip.zeros((b, s, s, 320), F16)
+    hip.conv_cin8(dev(hip, x8), dev(hip, w), dev(hip, bias), o)
+    hip.synchronize()
+    close(o, o_ref, 3e-3, 2e-3, "conv_cin8")
+    for c, co, mode in ((320, 4, 0), (128, 3, 1)):
+        x = rnd((b, s, s, c), 39, 1.0)
+        w = rnd((co, 9, c), 40, 1 / math.sqrt(9 * c) * (4.0 if mode else 1.0))
+        bias = rnd((co,), 41, 0.1, F32)
+        o_ref = torch.zeros(b, co, s, s, dtype=F32)
+        REF.conv_cout4(x, w, bias, o_ref, mode)
+        o = hip.zeros((b, co, s, s), F32)
+        hip.conv_cout4(dev(hip, x), dev(hip, w), dev(hip, bias), o, mode)
+        hip.synchronize()
+        close(o, o_ref, 1e-3, 1e-3, f"conv_cout4 c{c} mode{mode}")
+
+
+def test_time_rows_and_linear(hip):
+    t = torch.tensor([999, 978, 500, 20, 0], dtype=torch.int64)
+    f_ref = torch.zeros(5, 320)
+    REF.timestep_features(t, f_ref)
+    f = hip.zeros((5, 320), F32)
+    hip.timestep_features(dev(hip, t), f)
+    hip.synchronize()
+    close(f, f_ref, 2e-4, 0.0, "timestep features")   # |angle| up to 999 rad in fp32
+    for m, k, n, ai, ao in ((5, 320, 1280, 0, 1), (13, 1280, 1280, 0, 0), (50, 1280, 2000, 1, 0)):
+        x, w, bias = rnd((m, k), 42, 1.0, F32), rnd((n, k), 43, 1 / math.sqrt(k)), rnd((n,), 44, 0.1, F32)
+        o_ref = torch.zeros(m, n)
+        REF.linear_rows(x, w, bias, o_ref, ai, ao)
+        o = hip.zeros((m, n), F32)
+        hip.linear_rows(dev(hip, x), dev(hip, w), dev(hip, bias), o, ai, ao)
+        hip.synchronize()
+        close(o, o_ref, 2e-4, 2e-4, f"linear_rows {m}x{k}x{n}")
+
+
+def test_ddim_update_is_bit_exact(hip):
+    """The DDIM algebra is fp32 on both sides, op for op: the bar is bit-exactness."""
+    from oracle.sampler import OracleCfg, ddim_update, noise_schedule
+    _, ac, _, _ = noise_schedule(OracleCfg())
+    x, e, u = rnd((4, 4, 64, 64), 45, 1.0, F32), rnd((4, 4, 64, 64), 46, 1.0, F32), rnd((4, 4, 64, 64), 47, 1.0, F32)
+    for t, tp, last in ((999, 978, False), (500, 489, False), (20, 0, False), (0, None, True)):
+        a_t = ac[t]
+        coef = torch.stack([torch.sqrt(a_t), torch.sqrt(1 - a_t),
+                            torch.tensor(-1.0) if last else torch.sqrt(ac[tp]),
+                            torch.tensor(0.0) if last else torch.sqrt(1 - ac[tp])])
+        for eu, g in ((None, 1.0), (u, 3.0)):
+            eps = e if eu is None else eu + g * (e - eu)
+            ref = ddim_update(x, eps, ac, t, tp, last)
+            xd = dev(hip, x.clone())
+            hip.ddim_update(xd, dev(hip, e), dev(hip, eu), g, dev(hip, coef))
+            hip.synchronize()
+            assert torch.equal(xd.cpu(), ref), f"ddim t={t} cfg={eu is not None}"
+
+
+def test_begin_step_and_graph_replay(hip):
+    table, coef = rnd((6, 64), 48, 1.0, F32), rnd((6, 4), 49, 1.0, F32)
+    td, cd = dev(hip, table), dev(hip, coef)
+    cur, cc = hip.zeros((3, 64), F32), hip.zeros((4,), F32)
+    step = hip.zeros((1,), torch.int32)
+    acc = hip.zeros((1, 4, 1, 1), F32)
+    ones = dev(hip, torch.tensor([1.0, 0.0, 1.0, 1.0]))   # x <- clamp(x) + eps
+    eps = dev(hip, torch.full((1, 4, 1, 1), 0.25))
+    hip.graph_begin()
+    hip.begin_step(td, cur, cd, cc, step)
+    hip.ddim_update(acc, eps, None, 1.0, ones)
+    g = hip.graph_end()
+    for i in range(5):
+        hip.graph_launch(g)
+        hip.synchronize()
+        assert int(step.item()) == i + 1
+        assert torch.equal(cur.cpu(), table[i][None].expand(3, -1))
+        assert torch.equal(cc.cpu(), coef[i])
+    assert torch.allclose(acc.cpu(), torch.full((1, 4, 1, 1), 1.25))
+    hip.graph_destroy(g)
+
+
+def test_profiling_hooks(hip):
+    x, w = rnd((1, 256, 1, 320), 50), rnd((320, 320), 51, 0.05)
+    xd, wd, o = dev(hip, x), dev(hip, w), hip.zeros((1, 256, 1, 320), F16)
+    hip.prof_begin(1)
+    for _ in range(3):
+        hip.igemm(xd, wd, o)
+    st = hip.prof_end()
+    assert st["launches"] == 3 and st["ms"] > 0
+    assert st["flop"] == pytest.approx(3 * 2.0 * 256 * 320 * 320)
