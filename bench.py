@@ -49,28 +49,31 @@ def parse():
 
 
 def cpu_baseline(sd, image_size):
-    """The oracle (CPU port of the reference path) on a bounded sample of the same workload:
-    1 UNet call at B=1 + 1 VAE decode, extrapolated linearly to 50 steps (stated as extrapolated)."""
+    """The oracle (CPU port of the reference path) on a BOUNDED sample: 1 UNet eps call + 1 VAE
+    decode at B=1 on a 256x256 image (BASELINE configs[0] shape; ~20-40 s of CPU work), scaled to
+    the benchmark resolution by the analytic FLOP ratio and to 50 steps linearly — stated in `sample`."""
     from oracle.sd_unet import unet_forward
     from oracle.sd_vae import vae_decode
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)       # eager fp32 torch stops scaling well before 64 threads
     torch.set_num_threads(cores)
-    s = image_size // 8
+    flops = {256: (178.7, 622.2), 512: (800.8, 2514.5), 768: (2144.0, 5754.3)}   # GF/sample, SURVEY App. B
+    s = 32
     g = torch.Generator().manual_seed(0)
     x = torch.randn(1, 4, s, s, generator=g)
     cond = torch.randn(1, 48, 768, generator=g) * 0.5
-    t = torch.tensor([500])
     with torch.no_grad():
         t0 = time.perf_counter()
-        unet_forward(sd, x, t, cond, delta_scale=3.0)
+        unet_forward(sd, x, torch.tensor([500]), cond, delta_scale=3.0)
         t_unet = time.perf_counter() - t0
         t0 = time.perf_counter()
         vae_decode(sd, x)
         t_dec = time.perf_counter() - t0
-    per_image = 50 * t_unet + t_dec
-    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 UNet eps call (B=1, {image_size}x{image_size}) = {t_unet:.2f}s and 1 VAE decode = "
-                      f"{t_dec:.2f}s on the CPU oracle (fp32 torch), extrapolated to 50 steps + decode"}
+    fu, fd = flops.get(image_size, flops[512])
+    per_image = 50 * t_unet * fu / flops[256][0] + t_dec * fd / flops[256][1]
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (fp32 torch, {cores} threads): 1 UNet eps call at B=1, 256x256 = {t_unet:.2f}s, "
+                      f"1 VAE decode at 256x256 = {t_dec:.2f}s; scaled to {image_size}x{image_size} by the analytic "
+                      f"FLOP ratio ({fu}/{flops[256][0]} and {fd}/{flops[256][1]} GF) and to 50 steps linearly (extrapolated)"}
 
 
 def main():

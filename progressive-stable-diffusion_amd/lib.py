@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  torch's bundled HIP runtime must be the one in the process: load it first
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension is required (run __graft_entry__.build()); "
