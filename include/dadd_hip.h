@@ -35,6 +35,7 @@ extern "C" {
 #define DADD_EPI_ROWVEC 2   /* + rowvec[b][n]   (time-embedding projection of the sample) */
 #define DADD_EPI_RESIDUAL 4 /* + residual[m][n] */
 #define DADD_EPI_GEGLU 8    /* out[m][n/2] = hidden * gelu(gate); weight rows pre-interleaved */
+#define DADD_TUNE_SHALLOW 16 /* tuning: keep one K tile in flight instead of two (A/B measurements) */
 
 /* cross-attention modes of dadd_tri_xattn_f16 */
 #define DADD_XATTN_SPLIT 0    /* triple pathway, independent softmaxes */
@@ -72,6 +73,7 @@ typedef struct {
   int32_t taps, stride, ups, pad;
   int32_t ldo, ldr, ld_rowvec;
   int32_t splitk, flags, tile_n; /* tile_n: 128 or 160 (0 = choose) */
+  int32_t tile_m;                /* 64 or 128 (0 = 128): rows of the output tile */
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 
@@ -94,7 +96,7 @@ int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B, int C, int
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
  * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats.
  * Replaces nn.GroupNorm(+F.silu) in ResnetBlock2D / Transformer2DModel / VAE (+ torch.cat). */
-#define DADD_GN_MAX_CHUNKS 64
+#define DADD_GN_MAX_CHUNKS 256
 int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
                        const float* beta, void* out, float* ws, int B, int HW, int groups,
                        float eps, int silu, void* stream);

@@ -42,10 +42,13 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8;
 }
 
-template <int BN>
+template <int BM, int BN, bool DEEP>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
+  constexpr int WM = BM / 2;       // rows per wave (64 or 32)
+  constexpr int MI = WM / 16;      // m-fragments per wave (4 or 2)
   constexpr int WN = BN / 2;       // columns per wave
   constexpr int J = WN / 16;       // n-fragments per wave (4 or 5)
+  constexpr int NA = BM * 8 / 256; // 16-byte activation loads per thread per K tile
   constexpr int NB = BN * 8 / 256; // 16-byte weight loads per thread per K tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* As = reinterpret_cast<half_t*>(smem);
@@ -65,9 +68,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   const int Wv = p.ups ? 2 * p.Wi : p.Wi;
   const int HoWo = p.Ho * p.Wo;
 
-  int a_pix[4], a_y[4], a_x[4];
+  int a_pix[NA], a_y[NA], a_x[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NA; ++i) {
     const int m = m0 + r0 + 32 * i;
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
@@ -80,16 +83,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     a_x[i] = ox * p.stride - p.pad;
   }
 
-  f4 acc[J][4];
+  f4 acc[J][MI];
 #pragma unroll
   for (int j = 0; j < J; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
 
-  h8 ra[4], rb[NB];
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, h8 (&ra)[NA], h8 (&rb)[NB]) {
     const int kk = kt * BK;
     const int tap = kk / Cin;
     const int c = kk - tap * Cin;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     const int cs = second ? p.C2 : p.C1;
     const int cc = (second ? c - p.C1 : c) + q * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       int iy = a_y[i] + ky, ix = a_x[i] + kx;
       const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
       if (p.ups) {
@@ -116,11 +118,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
       rb[i] = (n < p.N) ? *reinterpret_cast<const h8*>(p.w + (size_t)n * p.K + kk + q * 8) : zero8;
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const h8 (&ra)[NA], const h8 (&rb)[NB]) {
     half_t* a = As + buf * BM * BK;
     half_t* b = Bs + buf * BN * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<h8*>(a + lds_off(r0 + 32 * i, q)) = ra[i];
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<h8*>(a + lds_off(r0 + 32 * i, q)) = ra[i];
 #pragma unroll
     for (int i = 0; i < NB; ++i) *reinterpret_cast<h8*>(b + lds_off(r0 + 32 * i, q)) = rb[i];
   };
@@ -130,40 +132,70 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int chunk = s * 4 + (lane >> 4);
-      h8 xa[4], wb[J];
+      h8 xa[MI], wb[J];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        xa[i] = *reinterpret_cast<const h8*>(a + lds_off(wm * 64 + i * 16 + (lane & 15), chunk));
+      for (int i = 0; i < MI; ++i)
+        xa[i] = *reinterpret_cast<const h8*>(a + lds_off(wm * WM + i * 16 + (lane & 15), chunk));
 #pragma unroll
       for (int j = 0; j < J; ++j)
         wb[j] = *reinterpret_cast<const h8*>(b + lds_off(wn * WN + j * 16 + (lane & 15), chunk));
 #pragma unroll
       for (int j = 0; j < J; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
     }
   };
 
-  if (kt0 < kt1) {
-    gload(kt0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
-    if (more) gload(kt + 1);
-    compute(cur);
-    if (more) lstore(cur ^ 1);
+  if constexpr (!DEEP) {
+    // one K tile in flight: fetch kt+1 into registers while kt feeds the MFMAs
+    h8 ra[NA], rb[NB];
+    if (kt0 < kt1) {
+      gload(kt0, ra, rb);
+      lstore(0, ra, rb);
+    }
     __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) gload(kt + 1, ra, rb);
+      compute(cur);
+      if (more) lstore(cur ^ 1, ra, rb);
+      __syncthreads();
+    }
+  } else {
+    // two K tiles in flight: while tile kt computes, tile kt+1 is already in registers (issued one
+    // iteration ago) and tile kt+2 is being fetched; loop unrolled by two so both register sets are
+    // statically named (runtime-indexed register arrays would go to scratch).
+    h8 raA[NA], rbA[NB], raB[NA], rbB[NB];
+    if (kt0 < kt1) {
+      gload(kt0, raA, rbA);
+      if (kt0 + 1 < kt1) gload(kt0 + 1, raB, rbB);
+      lstore(0, raA, rbA);
+    }
+    __syncthreads();
+    int kt = kt0;
+    while (kt < kt1) {
+      // even phase: LDS buf 0 holds kt, regs B hold kt+1, fetch kt+2 into regs A
+      if (kt + 2 < kt1) gload(kt + 2, raA, rbA);
+      compute(0);
+      if (kt + 1 < kt1) lstore(1, raB, rbB);
+      __syncthreads();
+      if (++kt >= kt1) break;
+      // odd phase: LDS buf 1 holds kt, regs A hold kt+1, fetch kt+2 into regs B
+      if (kt + 2 < kt1) gload(kt + 2, raB, rbB);
+      compute(1);
+      if (kt + 1 < kt1) lstore(0, raA, rbA);
+      __syncthreads();
+      ++kt;
+    }
   }
 
   // ---- epilogue: lane holds out[m][n .. n+3] for (i, j); m = column of the swapped MFMA result
   const int g = lane >> 4, mc = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + mc;
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WM + i * 16 + mc;
     if (m >= p.M) continue;
     const int b = m / HoWo;
     if (p.splitk > 1) {
@@ -244,29 +276,41 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
   }
 }
 
-template <int BN>
+template <int BM, int BN, bool DEEP>
 int set_attr() {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BN>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
 }
 
-template <int BN>
+template <int BM, int BN, bool DEEP>
 int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
   const int mtiles = (a.M + BM - 1) / BM;
   dim3 grid(mtiles * a.ntiles, nsplit);
-  hipLaunchKernelGGL(igemm_kernel<BN>, grid, dim3(256), smem, s, a);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, DEEP>), grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
+}
+
+template <int BM, int BN>
+int launch2(const IgemmArgs& a, int nsplit, bool deep, hipStream_t s) {
+  return deep ? launch<BM, BN, true>(a, nsplit, s) : launch<BM, BN, false>(a, nsplit, s);
 }
 
 }  // namespace
 
 int dadd_init_igemm() {
-  int rc = set_attr<128>();
-  return rc != DADD_OK ? rc : set_attr<160>();
+  int rc = DADD_OK;
+  if (rc == DADD_OK) rc = set_attr<128, 128, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 128, true>();
+  if (rc == DADD_OK) rc = set_attr<128, 160, false>();
+  if (rc == DADD_OK) rc = set_attr<64, 128, false>();
+  if (rc == DADD_OK) rc = set_attr<64, 128, true>();
+  if (rc == DADD_OK) rc = set_attr<64, 160, false>();
+  if (rc == DADD_OK) rc = set_attr<64, 160, true>();
+  return rc;
 }
 
 extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
@@ -284,7 +328,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags;
+  a.flags = d->flags & 15;
   const int Cin = a.C1 + a.C2;
   const bool geglu = (a.flags & DADD_EPI_GEGLU) != 0;
   a.ldo = d->ldo > 0 ? d->ldo : (geglu ? a.N / 2 : a.N);
@@ -332,7 +376,16 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
 
   const bool prof = dadd_prof_active(1);
   if (prof) dadd_prof_pre(s);
-  int rc = (tile_n == 160) ? launch<160>(a, nsplit, s) : launch<128>(a, nsplit, s);
+  // two K tiles in flight except where that spills (128x160) or when the caller asks for one
+  bool deep = (d->flags & DADD_TUNE_SHALLOW) == 0;
+  int tile_m = d->tile_m;
+  DADD_REQUIRE(tile_m == 0 || tile_m == 64 || tile_m == 128, "igemm: tile_m must be 0, 64 or 128");
+  if (tile_m == 0) tile_m = 128;
+  int rc;
+  if (tile_m == 128)
+    rc = (tile_n == 160) ? launch<128, 160, false>(a, nsplit, s) : launch2<128, 128>(a, nsplit, deep, s);
+  else
+    rc = (tile_n == 160) ? launch2<64, 160>(a, nsplit, deep, s) : launch2<64, 128>(a, nsplit, deep, s);
   if (prof) dadd_prof_post(s, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (rc != DADD_OK) return rc;
   if (nsplit > 1) {

@@ -14,7 +14,7 @@ struct GnArgs {
   const float* beta;
   half_t* out;
   float* ws;  // [B][nchunk][groups][2]
-  int C1, C2, C, HW, groups, cg, nchunk, rows_per_chunk, TV, RP, silu;
+  int C1, C2, C, HW, groups, cg, nchunk, rows_per_chunk, rows_per_block, TV, RP, silu;
   float eps;
 };
 
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
   }
 }
 
-// pass 2: finish the statistics (double), fold gamma/beta into per-channel scale/shift, apply.
+// pass 2: finish the statistics (8 threads per group, fixed order, double), fold gamma/beta into
+// per-channel scale/shift, apply to this block's rows.  grid (row blocks, B)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
   extern __shared__ float sm[];  // [C] scale, [C] shift, [groups] mean, [groups] rstd
   float* scale = sm;
@@ -87,20 +88,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
   float* mean = sm + 2 * p.C;
   float* rstd = mean + p.groups;
   const int t = threadIdx.x, tv = t % p.TV, tr = t / p.TV;
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  if (t < p.groups) {
+  const int b = blockIdx.y;
+  {
+    const int g = t >> 3, sub = t & 7;
     double a = 0.0, q = 0.0;
-    for (int k = 0; k < p.nchunk; ++k) {
-      const float* w = p.ws + (((size_t)b * p.nchunk + k) * p.groups + t) * 2;
-      a += (double)w[0];
-      q += (double)w[1];
+    if (g < p.groups) {
+      for (int k = sub; k < p.nchunk; k += 8) {
+        const float* w = p.ws + (((size_t)b * p.nchunk + k) * p.groups + g) * 2;
+        a += (double)w[0];
+        q += (double)w[1];
+      }
     }
-    const double n = (double)p.HW * (double)p.cg;
-    const double mu = a / n;
-    double var = q / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[t] = (float)mu;
-    rstd[t] = (float)(1.0 / sqrt(var + (double)p.eps));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (g < p.groups && sub == 0) {
+      const double n = (double)p.HW * (double)p.cg;
+      const double mu = a / n;
+      double var = q / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      mean[g] = (float)mu;
+      rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
   }
   __syncthreads();
   for (int c = t; c < p.C; c += 256) {
@@ -112,8 +123,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
   __syncthreads();
   if (tr >= p.RP) return;
   const int nvec = p.C >> 3;
-  const int row0 = chunk * p.rows_per_chunk;
-  const int row1 = min(p.HW, row0 + p.rows_per_chunk);
+  const int row0 = blockIdx.x * p.rows_per_block;
+  const int row1 = min(p.HW, row0 + p.rows_per_block);
   for (int row = row0 + tr; row < row1; row += p.RP) {
     const size_t pix = (size_t)b * p.HW + row;
 #pragma unroll
@@ -199,7 +210,7 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   DADD_REQUIRE(x1 && gamma && beta && out && ws, "groupnorm: null pointer");
   DADD_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0, "groupnorm: C1/C2 must be x8");
   DADD_REQUIRE(C2 == 0 || x2, "groupnorm: C2>0 needs x2");
-  DADD_REQUIRE(groups > 0 && groups <= 256 && C % groups == 0, "groupnorm: C %% groups != 0");
+  DADD_REQUIRE(groups > 0 && groups <= 32 && C % groups == 0, "groupnorm: groups must be <= 32 and divide C");
   DADD_REQUIRE(C <= 8 * 256 * GN_MAXV, "groupnorm: C=%d too large", C);
   DADD_REQUIRE(B > 0 && HW > 0, "groupnorm: empty input");
   DADD_REQUIRE(dadd_aligned16(x1) && dadd_aligned16(out) && (!x2 || dadd_aligned16(x2)),
@@ -216,17 +227,20 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const int nvec = C / 8;
   p.TV = nvec < 256 ? nvec : 256;
   p.RP = 256 / p.TV;
-  int nchunk = HW / 32;
+  // enough blocks to cover the 256 CUs several times over, at least 2 passes of rows per block
+  int nchunk = HW / (2 * p.RP > 16 ? 2 * p.RP : 16);
   if (nchunk < 1) nchunk = 1;
   if (nchunk > DADD_GN_MAX_CHUNKS) nchunk = DADD_GN_MAX_CHUNKS;
   p.rows_per_chunk = (HW + nchunk - 1) / nchunk;
   p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  p.rows_per_block = 4 * p.RP;
+  const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t sm1 = (size_t)2 * p.RP * C * sizeof(float);
   const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, B), dim3(256), sm1, s, p);
   DADD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(p.nchunk, B), dim3(256), sm2, s, p);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nrb, B), dim3(256), sm2, s, p);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

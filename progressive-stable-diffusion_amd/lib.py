@@ -16,8 +16,9 @@ SOURCES = ("igemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+TUNE_SHALLOW = 16
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
-GN_MAX_CHUNKS = 64
+GN_MAX_CHUNKS = 256
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -27,7 +28,7 @@ class IgemmDesc(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "x2", "w", "out", "partial", "bias", "rowvec", "residual")] + \
                [(n, i32) for n in ("B", "Hi", "Wi", "C1", "C2", "Ho", "Wo", "N", "taps", "stride",
                                    "ups", "pad", "ldo", "ldr", "ld_rowvec", "splitk", "flags",
-                                   "tile_n")]
+                                   "tile_n", "tile_m")]
 
 
 # name -> (restype, argtypes); every symbol include/dadd_hip.h declares

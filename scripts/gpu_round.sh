@@ -23,6 +23,8 @@ for s in $steps; do
     kernels) run kernels 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=300 ;;
     parity)  run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 ;;
     smoke)   run smoke 300 python __graft_entry__.py smoke ;;
+    opbench) TAILN=80 run opbench 600 python scripts/op_bench.py "$tag" ;;
+    opbenchvae) TAILN=60 run opbenchvae 600 python scripts/op_bench.py "$tag" --vae ;;
     bench)   run bench 900 python bench.py --steps 2 --warmup 1 ;;
     prof)    export TMPDIR=/tmp
              run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline

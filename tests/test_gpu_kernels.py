@@ -131,7 +131,7 @@ def test_groupnorm(hip, c1, c2, hw, silu, eps):
     o_ref = torch.zeros(b, side, side, c, dtype=F16)
     REF.groupnorm(x1, x2, gamma, beta, o_ref, None, 32, eps, silu)
     o = hip.zeros((b, side, side, c), F16)
-    ws = hip.zeros((b * 64 * 32 * 2,), F32)
+    ws = hip.zeros((b * 256 * 32 * 2,), F32)
     hip.groupnorm(dev(hip, x1), dev(hip, x2), dev(hip, gamma), dev(hip, beta), o, ws, 32, eps, silu)
     hip.synchronize()
     close(o, o_ref, 3e-3, 2e-3, f"groupnorm c{c1}+{c2} hw{hw}")
