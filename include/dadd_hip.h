@@ -36,6 +36,7 @@ extern "C" {
 #define DADD_EPI_RESIDUAL 4 /* + residual[m][n] */
 #define DADD_EPI_GEGLU 8    /* out[m][n/2] = hidden * gelu(gate); weight rows pre-interleaved */
 #define DADD_TUNE_SHALLOW 16 /* tuning: keep one K tile in flight instead of two (A/B measurements) */
+#define DADD_TUNE_NODMA 32   /* tuning: register-staged kernel instead of the LDS-DMA ring kernel */
 
 /* cross-attention modes of dadd_tri_xattn_f16 */
 #define DADD_XATTN_SPLIT 0    /* triple pathway, independent softmaxes */

@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   constexpr int KLD = D + 8, VLD = v_stride(DVP);
   constexpr int NL = (64 * DC + 255) / 256;  // 16-byte loads per thread per tile per tensor
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // PREFETCH variants double-buffer the K/V tiles (one barrier per tile); buffer b at KsB(b)/VsB(b)
+  constexpr int NBUFS = PREFETCH ? 2 : 1;
+  constexpr int TILE_HALFS = 64 * (KLD + VLD);
   half_t* Ks = reinterpret_cast<half_t*>(smem);
   half_t* Vs = Ks + 64 * KLD;
 
@@ -67,8 +70,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // zero the padding columns once (K: [DR,D), V: [DR,DVP)); tile stores never touch them
-  for (int i = t; i < 64 * KLD / 8; i += 256) *reinterpret_cast<h8*>(Ks + i * 8) = zero8;
-  for (int i = t; i < 64 * VLD / 8; i += 256) *reinterpret_cast<h8*>(Vs + i * 8) = zero8;
+  for (int i = t; i < NBUFS * TILE_HALFS / 8; i += 256) *reinterpret_cast<h8*>(Ks + i * 8) = zero8;
 
   // Q fragments (B operand of S^T = K Q^T): lane -> query li, d-chunk 32s + 8g
   h8 qf[QF][KS];
@@ -109,14 +111,14 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
       rv[u] = ok ? *reinterpret_cast<const h8*>(p.v + off) : zero8;
     }
   };
-  auto tile_store = [&]() {
+  auto tile_store = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const int idx = t + 256 * u;
       const int row = idx / DC, ch = idx - row * DC;
       if (idx < 64 * DC) {
-        *reinterpret_cast<h8*>(Ks + row * KLD + ch * 8) = rk[u];
-        *reinterpret_cast<h8*>(Vs + row * VLD + ch * 8) = rv[u];
+        *reinterpret_cast<h8*>(Ks + buf * TILE_HALFS + row * KLD + ch * 8) = rk[u];
+        *reinterpret_cast<h8*>(Vs + buf * TILE_HALFS + row * VLD + ch * 8) = rv[u];
       }
     }
   };
@@ -133,12 +135,24 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
     }
   };
 
-  if (PREFETCH) tile_load(0);
+  const bool ragged = (p.N & 63) != 0;
+  if (PREFETCH) {
+    tile_load(0);
+    __syncthreads();   // zero fill done
+    tile_store(0);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // everyone finished reading the previous tile (and the initial zero fill)
-    if (PREFETCH) tile_store(); else tile_direct(kt);
-    __syncthreads();
-    if (PREFETCH && kt + 1 < nkt) tile_load(kt + 1);
+    const int buf = PREFETCH ? (kt & 1) : 0;
+    const half_t* Kc = Ks + buf * TILE_HALFS;
+    const half_t* Vc = Vs + buf * TILE_HALFS;
+    if (PREFETCH) {
+      __syncthreads();   // tile kt visible; everyone finished reading tile kt-1 (the other buffer)
+      if (kt + 1 < nkt) tile_load(kt + 1);
+    } else {
+      __syncthreads();
+      tile_direct(kt);
+      __syncthreads();
+    }
 
     // ---- S^T = K Q^T : sacc[kf][f], rows = keys kf*16 + 4g + r, column = query li
     f4 sacc[4][QF];
@@ -150,47 +164,56 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf) {
-        const h8 ka = *reinterpret_cast<const h8*>(Ks + (kf * 16 + li) * KLD + 32 * s + 8 * g);
+        const h8 ka = *reinterpret_cast<const h8*>(Kc + (kf * 16 + li) * KLD + 32 * s + 8 * g);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
           sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], sacc[kf][f], 0, 0, 0);
       }
     }
 
-    // ---- online softmax per query column
+    // ---- online softmax per query column.  Scores stay unscaled in the accumulator; the scale is
+    // fused into the exponent (one fma + one v_exp_f32 per score).  The key mask runs only on a
+    // ragged last tile, and O is rescaled only when some row maximum actually moved.
     h8 pb[QF][2];
     const int kbase = kt * 64 + 4 * g;
+    const bool mask_tile = ragged && (kt == nkt - 1);
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      float mx = -1e30f;
+      if (mask_tile) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + kf * 16 + r >= p.N) sacc[kf][f][r] = -3.0e38f;
+      }
+      float mx = -3.0e38f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sv = sacc[kf][f][r] * p.scale_log2;
-          if (kbase + kf * 16 + r >= p.N) sv = -1e30f;
-          sacc[kf][f][r] = sv;
-          mx = fmaxf(mx, sv);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kf][f][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrow[f], mx);
-      const float alpha = exp2f(mrow[f] - mnew);
+      const float mnew = fmaxf(mrow[f], mx * p.scale_log2);      // running max in log2 units
+      const bool moved = mnew > mrow[f];
       float rs = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f(sacc[kf][f][r] - mnew);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][r], p.scale_log2, -mnew));
           sacc[kf][f][r] = pv;
           rs += pv;
         }
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
-      lrow[f] = lrow[f] * alpha + rs;
-      mrow[f] = mnew;
+      if (__any(moved)) {                                        // wave-uniform branch
+        const float alpha = __builtin_amdgcn_exp2f(mrow[f] - mnew);
+        lrow[f] *= alpha;
 #pragma unroll
-      for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
+        for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
+      }
+      lrow[f] += rs;
+      mrow[f] = mnew;
       pb[f][0] = pack_p(sacc[0][f], sacc[1][f]);
       pb[f][1] = pack_p(sacc[2][f], sacc[3][f]);
     }
@@ -200,13 +223,14 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
     for (int df = 0; df < DF; ++df) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const half_t* base = Vs + (kb * 32 + 4 * g + (li >> 2)) * VLD + df * 16 + 4 * (li & 3);
+        const half_t* base = Vc + (kb * 32 + 4 * g + (li >> 2)) * VLD + df * 16 + 4 * (li & 3);
         const h8 va = tr_pair(base, base + 16 * VLD);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
           oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[f][kb], oacc[df][f], 0, 0, 0);
       }
     }
+    if (PREFETCH && kt + 1 < nkt) tile_store(buf ^ 1);   // last read of that buffer was tile kt-1
   }
 
   // ---- normalise and store: lane owns O[q = li][d = df*16 + 4g .. +3]
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
 template <int DR, int QF, bool PF>
 int flash_attr() {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
-  constexpr int smem = 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
+  constexpr int smem = (PF ? 2 : 1) * 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
   DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<DR, QF, PF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
@@ -399,7 +423,7 @@ int flash_attr() {
 template <int DR, int QF, bool PF>
 int launch_flash(const FlashArgs& a, hipStream_t s) {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
-  constexpr int smem = 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
+  constexpr int smem = (PF ? 2 : 1) * 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
   dim3 grid((a.N + 64 * QF - 1) / (64 * QF), a.B * a.H);
   hipLaunchKernelGGL((flash_kernel<DR, QF, PF>), grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();

@@ -14,24 +14,9 @@
 // Zero padding, stride 2, the asymmetric VAE-encoder padding, nearest-2x upsampling and the
 // skip-connection concat are all folded into the A-tile address generation.
 #include "dadd_common.h"
+#include "igemm_args.h"
 
 namespace {
-
-struct IgemmArgs {
-  const half_t* x;
-  const half_t* x2;
-  const half_t* w;
-  half_t* out;
-  float* partial;
-  const float* bias;
-  const float* rowvec;
-  const half_t* residual;
-  int B, Hi, Wi, C1, C2, Ho, Wo, N;
-  int taps, stride, ups, pad;
-  int ldo, ldr, ld_rowvec;
-  int splitk, flags;
-  int M, K, nkt, kps, ntiles;
-};
 
 constexpr int BM = 128;
 constexpr int BK = 64;
@@ -56,7 +41,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int nt = blockIdx.x % p.ntiles, mt = blockIdx.x / p.ntiles;
+  const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = tile_id % p.ntiles, mt = tile_id / p.ntiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int z = blockIdx.y;
   const int kt0 = z * p.kps;
@@ -302,7 +288,7 @@ int launch2(const IgemmArgs& a, int nsplit, bool deep, hipStream_t s) {
 }  // namespace
 
 int dadd_init_igemm() {
-  int rc = DADD_OK;
+  int rc = dadd_init_igemm_dma();
   if (rc == DADD_OK) rc = set_attr<128, 128, false>();
   if (rc == DADD_OK) rc = set_attr<128, 128, true>();
   if (rc == DADD_OK) rc = set_attr<128, 160, false>();
@@ -382,7 +368,12 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   DADD_REQUIRE(tile_m == 0 || tile_m == 64 || tile_m == 128, "igemm: tile_m must be 0, 64 or 128");
   if (tile_m == 0) tile_m = 128;
   int rc;
-  if (tile_m == 128)
+  // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
+  // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
+  const bool dma = tile_m == 128 && (d->flags & DADD_TUNE_NODMA) == 0;
+  if (dma)
+    rc = dadd_launch_igemm_dma(a, tile_n, nsplit, s);
+  else if (tile_m == 128)
     rc = (tile_n == 160) ? launch<128, 160, false>(a, nsplit, s) : launch2<128, 128>(a, nsplit, deep, s);
   else
     rc = (tile_n == 160) ? launch2<64, 160>(a, nsplit, deep, s) : launch2<64, 128>(a, nsplit, deep, s);

@@ -71,26 +71,22 @@ def geglu_interleave(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, to
     return w[src].contiguous(), b[src].contiguous()
 
 
-def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> Tuple[int, int]:
-    """(tile_m, splitk) for one implicit GEMM.  Measured on MI355X over every layer shape of the
-    B=4 / 512x512 step (scripts/op_bench.py, profiles/r01_b_op_bench.txt): the kernel wants ~2 blocks
-    per CU (~512 blocks).  Large-K convolutions keep the 128-row tile and split K to get there;
-    short-K linears use the 64-row tile instead (a split would leave < 5 K tiles per slab and the
-    slab pass costs more than it buys); the 8x8 level needs both."""
+def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> Tuple[int, int, int]:
+    """(tile_m, splitk, tune_flags) for one implicit GEMM, from measurements over every layer shape
+    of the B=4 / 512x512 step on MI355X (scripts/op_bench.py, profiles/r01_*_op_bench.txt):
+      * K >= 16 tiles: the LDS-DMA ring kernel, 128-row tiles, ONE block per CU (it hides latency with
+        its ring, not with occupancy) -> split K until the grid reaches ~256 blocks;
+      * short K (<= 960) and the GEGLU projection: the register-staged kernel, two blocks per CU,
+        64-row tiles when 128-row tiles would not give ~512 blocks."""
     nkt = k // 64
     nt = math.ceil(n / tile_n)
     t128 = math.ceil(m / 128) * nt
-    if t128 >= 2 * N_CU:
-        return 128, 1
-    t64 = math.ceil(m / 64) * nt
     if geglu:
-        return (64 if t128 < 2 * N_CU else 128), 1
-    if nkt >= 40 and t128 >= 32:                       # 3x3 convolutions with enough row tiles
-        return 128, max(1, min(math.ceil(2 * N_CU / t128), nkt // 8, 32))
-    sk = 1
-    if t64 < 192:
-        sk = max(1, min(math.ceil(1.5 * N_CU / t64), nkt // 5, 32))
-    return 64, sk
+        return 64, 1, L.TUNE_NODMA | L.TUNE_SHALLOW
+    if nkt >= 16:
+        sk = max(1, min(round(N_CU / t128), nkt // 5, 32))
+        return 128, sk, 0
+    return (128 if t128 >= 2 * N_CU else 64), 1, L.TUNE_NODMA
 
 
 def choose_splitk(m: int, n: int, k: int, tile_n: int) -> int:
@@ -147,10 +143,10 @@ class _Plan:
         n = w.shape[0]
         tile_n = 128 if (flags & L.EPI_GEGLU) or n % 160 else 160
         m = out_shape[0] * out_shape[1] * out_shape[2]
-        tile_m, sk = choose_tiling(m, n, w.shape[1], tile_n, bool(flags & L.EPI_GEGLU))
+        tile_m, sk, tune = choose_tiling(m, n, w.shape[1], tile_n, bool(flags & L.EPI_GEGLU))
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
-            | (L.EPI_RESIDUAL if residual is not None else 0)
+            | (L.EPI_RESIDUAL if residual is not None else 0) | tune
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
                  taps=taps, stride=stride, ups=ups, pad=pad, flags=f, splitk=sk, partial=partial,
                  tile_n=tile_n, tile_m=tile_m)

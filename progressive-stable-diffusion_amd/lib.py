@@ -12,11 +12,11 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdadd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("igemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip")
+SOURCES = ("igemm.hip", "igemm_dma.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip")
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
-TUNE_SHALLOW = 16
+TUNE_SHALLOW, TUNE_NODMA = 16, 32
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
 GN_MAX_CHUNKS = 256
 
@@ -68,7 +68,7 @@ _lib: Optional[C.CDLL] = None
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into ``libdadd_hip.so`` (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "dadd_common.h"),
+    deps = srcs + [os.path.join(CSRC, "dadd_common.h"), os.path.join(CSRC, "igemm_args.h"),
                    os.path.join(os.path.dirname(_HERE), "include", "dadd_hip.h")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):

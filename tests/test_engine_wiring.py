@@ -50,17 +50,19 @@ def test_geglu_interleave_roundtrip():
 
 
 def test_splitk_heuristic():
-    # policy measured with scripts/op_bench.py on MI355X (profiles/r01_b_op_bench.txt)
-    assert E.choose_tiling(16384, 2560, 320, 128, geglu=True) == (128, 1)   # big grid: plain 128-row tiles
-    assert E.choose_tiling(16384, 320, 320, 160) == (64, 1)                # short-K linear: 64-row tiles
-    assert E.choose_tiling(16384, 320, 5760, 160) == (128, 2)              # 64x64 conv: 256 tiles -> split 2
-    assert E.choose_tiling(4096, 640, 5760, 160) == (128, 4)
-    assert E.choose_tiling(1024, 1280, 11520, 160) == (128, 8)
-    tm, sk = E.choose_tiling(256, 1280, 11520, 160)                          # 8x8 level needs both
-    assert tm == 64 and sk >= 8
-    assert E.choose_splitk(64, 1280, 768, 160) <= 3
+    # policy measured with scripts/op_bench.py on MI355X (profiles/r01_*_op_bench.txt)
+    from progressive_stable_diffusion_amd import lib as L
+    assert E.choose_tiling(16384, 2560, 320, 128, geglu=True) == (64, 1, L.TUNE_NODMA | L.TUNE_SHALLOW)
+    assert E.choose_tiling(16384, 320, 320, 160) == (64, 1, L.TUNE_NODMA)   # short-K linear: register kernel
+    assert E.choose_tiling(16384, 960, 320, 160) == (128, 1, L.TUNE_NODMA)
+    assert E.choose_tiling(16384, 320, 5760, 160) == (128, 1, 0)           # 256 tiles: one per CU, DMA ring
+    assert E.choose_tiling(4096, 640, 5760, 160) == (128, 2, 0)
+    assert E.choose_tiling(1024, 1280, 11520, 160) == (128, 4, 0)
+    assert E.choose_tiling(256, 1280, 11520, 160) == (128, 16, 0)           # 8x8 level: 16 tiles x 16 splits
+    assert E.choose_tiling(1024, 1280, 1280, 160) == (128, 4, 0)
+    assert E.choose_splitk(64, 1280, 768, 160) == 1
     for m, n, k in ((256, 1280, 23040), (1024, 640, 5760), (4096, 640, 5760), (1024, 1280, 1280)):
-        tm, s = E.choose_tiling(m, n, k, 160)
+        tm, s, _ = E.choose_tiling(m, n, k, 160)
         assert tm in (64, 128) and 1 <= s <= 32 and (k // 64) // s >= 4
 
 

@@ -99,6 +99,31 @@ def test_igemm_splitk_matches_single_pass(hip, splitk):
     close(o, o_ref, 3e-3, 2e-3, f"splitk {splitk}")
 
 
+@pytest.mark.parametrize("tile_m,tune,splitk", [(128, 0, 1), (128, 0, 3), (128, 32, 1), (128, 32 | 16, 1),
+                                                (64, 0, 1), (64, 16, 1), (64, 0, 5), (128, 32, 4)])
+@pytest.mark.parametrize("shape", ["conv", "cat1x1", "ups", "ragged"])
+def test_igemm_kernel_variants(hip, tile_m, tune, splitk, shape):
+    """Every kernel variant the tiling policy can pick (LDS-DMA ring, register-staged with one or two
+    K tiles in flight, 64/128-row tiles, split-K) on the same problems; tune: 16=shallow, 32=no DMA."""
+    b = 2
+    if shape == "conv":
+        h, c1, c2, n, taps, ups, ho = 12, 320, 0, 320, 9, 0, 12
+    elif shape == "cat1x1":
+        h, c1, c2, n, taps, ups, ho = 16, 640, 320, 640, 1, 0, 16
+    elif shape == "ups":
+        h, c1, c2, n, taps, ups, ho = 8, 640, 0, 640, 9, 1, 16
+    else:                                   # M = 2*7*7 = 98 rows: a single, mostly empty row tile
+        h, c1, c2, n, taps, ups, ho = 7, 1280, 1280, 1280, 9, 0, 7
+    x = rnd((b, h, h, c1), 60)
+    x2 = rnd((b, h, h, c2), 61) if c2 else None
+    k = taps * (c1 + c2)
+    w = rnd((n, k), 62, 1 / math.sqrt(k))
+    bias, res = rnd((n,), 63, 0.1, F32), rnd((b, ho, ho, n), 64)
+    o, o_ref = run_igemm(hip, x, w, (b, ho, ho, n), x2=x2, bias=bias, residual=res, taps=taps, ups=ups,
+                         pad=taps // 9, flags=5 | tune, splitk=splitk, tile_m=tile_m)
+    close(o, o_ref, 3e-3, 2e-3, f"{shape} tm{tile_m} tune{tune} sk{splitk}")
+
+
 def test_igemm_geglu(hip):
     from progressive_stable_diffusion_amd.engine import geglu_interleave
     m, c = 300, 320

@@ -109,6 +109,7 @@ class TorchRefBackend:
             y = F.conv2d(xn, wt, None, stride=stride, padding=pad)
         assert y.shape[2] == ho and y.shape[3] == wo, (y.shape, out.shape)
         y = y.permute(0, 2, 3, 1)
+        flags &= 15                     # tuning bits (16, 32) do not change the math
         if flags & EPI_BIAS:
             y = y + bias.float()
         if flags & EPI_ROWVEC:
