@@ -35,11 +35,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN>
+template <int BN, bool UPS>
 __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type exists only in device code; the host
                                       // pass needs just the launch stub of this signature
-  constexpr int NBUF = 4;
   constexpr int WN = BN / 2;
   constexpr int J = WN / 16;
   constexpr int NA = BM / 32;   // DMA instructions per wave per tile, activations (4)
@@ -59,27 +58,26 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   const int kt1 = min(p.nkt, kt0 + p.kps);
   const int nk = kt1 - kt0;
   const int Cin = p.C1 + p.C2;
-  const int Hv = p.ups ? 2 * p.Hi : p.Hi;
-  const int Wv = p.ups ? 2 * p.Wi : p.Wi;
+  const int Hv = UPS ? 2 * p.Hi : p.Hi;
+  const int Wv = UPS ? 2 * p.Wi : p.Wi;
   const int HoWo = p.Ho * p.Wo;
   const int lrow = lane >> 3, lch = lane & 7;
 
   // Buffer descriptors.  For the affine gathers (everything but the 2x-upsample) the "-pad" of the
   // window origin is folded into the descriptor base, so per-lane offsets and the per-tap scalar
   // offset are both non-negative; lanes whose tap falls outside the image get voffset = OOB.
-  const int shift1 = p.ups ? 0 : (p.pad * p.Wi + p.pad) * p.C1;
-  const int shift2 = p.ups ? 0 : (p.pad * p.Wi + p.pad) * p.C2;
+  const int shift1 = UPS ? 0 : (p.pad * p.Wi + p.pad) * p.C1;
+  const int shift2 = UPS ? 0 : (p.pad * p.Wi + p.pad) * p.C2;
   const size_t pix_total = (size_t)p.B * p.Hi * p.Wi;
-  const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x - shift1), 0, (int)((pix_total * p.C1 + shift1) * 2), 0x00020000);
-  const auto rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((p.x2 ? p.x2 : p.x) - shift2), 0, (int)((pix_total * p.C2 + shift2) * 2), 0x00020000);
-  const auto rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((size_t)p.N * p.K * 2),
-                                                       0x00020000);
+  const int rec1 = (int)((pix_total * p.C1 + shift1) * 2);
+  const int rec2 = (int)((pix_total * p.C2 + shift2) * 2);
+  const int recW = (int)((size_t)p.N * p.K * 2);
+  const half_t* base1 = p.x - shift1;
+  const half_t* base2 = (p.x2 ? p.x2 : p.x) - shift2;
 
   // per-lane gather state: byte offsets of the window origin in both sources, validity bit per tap
   unsigned a_v1[NA], a_v2[NA], a_mask[NA];
-  int a_pix[NA], a_y[NA], a_x[NA], a_cc[NA];   // only the upsample path needs these per tile
+  int a_pix[NA], a_y[NA], a_x[NA], a_cc[NA];   // only the upsample path uses these per tile
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = (i * 4 + wave) * 8 + lrow;
@@ -114,46 +112,59 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
     w_v[j] = (n < p.N) ? (unsigned)(((size_t)n * p.K + (lch ^ ((row >> 1) & 7)) * 8) * 2) : OOB;
   }
 
-  auto issue = [&](int kt, int slot) {   // LPT DMA loads for K tile kt into ring slot `slot`
-    const int kk = kt * BK;
-    const int tap = kk / Cin;
-    const int c = kk - tap * Cin;
-    const int ky = (p.taps == 9) ? tap / 3 : 0;
-    const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
-    const bool second = c >= p.C1;
+  // ---- wave-uniform tile cursor, advanced incrementally (no divisions in the loop): K tile -> tap,
+  // (ky, kx), channel offset; plus the byte offsets of the ring slots being filled / computed.
+  int cur_kt = kt0;
+  int cur_tap = (kt0 * BK) / Cin;
+  int cur_c = kt0 * BK - cur_tap * Cin;
+  int cur_ky = (p.taps == 9) ? cur_tap / 3 : 0;
+  int cur_kx = (p.taps == 9) ? cur_tap - 3 * cur_ky : 0;
+  int fill_off = wave * 1024;                 // LDS byte offset of this wave's share of the slot to fill
+
+  auto issue = [&]() {   // LPT DMA loads for K tile cur_kt into the slot at fill_off, then advance
+    const bool live = cur_kt < kt1;           // past the end: zero-record descriptors, no memory traffic
+    const bool second = cur_c >= p.C1;
     const int cs = second ? p.C2 : p.C1;
-    const int cb = second ? c - p.C1 : c;
-    char* sa = smem + slot * STAGE + wave * 1024;
-    if (!p.ups) {
-      const unsigned soff = (unsigned)(((ky * p.Wi + kx) * cs + cb) * 2);
+    const int cb = second ? cur_c - p.C1 : cur_c;
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? base2 : base1), 0,
+                                                       live ? (second ? rec2 : rec1) : 0, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
+    char* sa = smem + fill_off;
+    if constexpr (!UPS) {
+      const unsigned soff = (unsigned)(((cur_ky * p.Wi + cur_kx) * cs + cb) * 2);
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const bool ok = (a_mask[i] >> tap) & 1u;
-        if (second)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc2, (lptr_t)(sa + i * 4096), 16,
-                                                   ok ? a_v2[i] : OOB, soff, 0, 0);
-        else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lptr_t)(sa + i * 4096), 16,
-                                                   ok ? a_v1[i] : OOB, soff, 0, 0);
+        const bool ok = (a_mask[i] >> cur_tap) & 1u;
+        const unsigned vo = second ? a_v2[i] : a_v1[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sa + i * 4096), 16, ok ? vo : OOB, soff, 0, 0);
       }
     } else {   // nearest-2x upsample: the source pixel is (iy>>1, ix>>1) of the virtual image
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const int iy = a_y[i] + cur_ky, ix = a_x[i] + cur_kx;
         const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
         const unsigned vo = (unsigned)(((a_pix[i] + (iy >> 1) * p.Wi + (ix >> 1)) * cs + a_cc[i]) * 2);
-        if (second)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc2, (lptr_t)(sa + i * 4096), 16, ok ? vo : OOB,
-                                                   (unsigned)(cb * 2), 0, 0);
-        else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lptr_t)(sa + i * 4096), 16, ok ? vo : OOB,
-                                                   (unsigned)(cb * 2), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sa + i * 4096), 16, ok ? vo : OOB,
+                                                 (unsigned)(cb * 2), 0, 0);
       }
     }
+    const unsigned koff = (unsigned)(cur_kt * (BK * 2));
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, (lptr_t)(sa + A_BYTES + j * 4096), 16, w_v[j],
-                                               (unsigned)(kk * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(sa + A_BYTES + j * 4096), 16, w_v[j], koff, 0, 0);
+    // advance the cursor with selects only: a branch here would split the loop body into two
+    // scheduling regions and the DMA issue could not be interleaved with the MFMAs
+    ++cur_kt;
+    const int c1 = cur_c + BK;
+    const int wrap = c1 >= Cin ? 1 : 0;
+    cur_c = wrap ? 0 : c1;
+    cur_tap += wrap;
+    const int kx1 = cur_kx + wrap;
+    const int w3 = kx1 == 3 ? 1 : 0;
+    cur_kx = w3 ? 0 : kx1;
+    cur_ky += w3;
+    const int f1 = fill_off + STAGE;
+    fill_off = f1 >= 4 * STAGE ? f1 - 4 * STAGE : f1;
   };
 
   f4 acc[J][4];
@@ -162,16 +173,22 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads of one 32-deep K step (s = 0,1) of a ring slot, and the MFMAs that consume them
-  const int frow_a = wm * 64 + (lane & 15), frow_b = wn * WN + (lane & 15), fq = lane >> 4;
-  auto read_frags = [&](int slot, int s, h8 (&xa)[4], h8 (&wb)[J]) {
-    const half_t* a = reinterpret_cast<const half_t*>(smem + slot * STAGE);
-    const half_t* b = reinterpret_cast<const half_t*>(smem + slot * STAGE + A_BYTES);
-    const int chunk = s * 4 + fq;
+  // fragment addresses inside a slot: per lane one byte offset per operand and K half (the XOR swizzle
+  // term is the same for all 16-row fragments of a wave), fragment i / j adds an immediate i*2048.
+  const int fq = lane >> 4;
+  int fa[2], fb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const h8*>(a + lds_off(frow_a + i * 16, chunk));
+  for (int s = 0; s < 2; ++s) {
+    fa[s] = lds_off(wm * 64 + (lane & 15), s * 4 + fq) * 2;
+    fb[s] = A_BYTES + lds_off(wn * WN + (lane & 15), s * 4 + fq) * 2;
+  }
+  auto read_frags = [&](int slot_off, int s, h8 (&xa)[4], h8 (&wb)[J]) {
+    const char* a = smem + slot_off + fa[s];
+    const char* b = smem + slot_off + fb[s];
 #pragma unroll
-    for (int j = 0; j < J; ++j) wb[j] = *reinterpret_cast<const h8*>(b + lds_off(frow_b + j * 16, chunk));
+    for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const h8*>(a + i * 2048);
+#pragma unroll
+    for (int j = 0; j < J; ++j) wb[j] = *reinterpret_cast<const h8*>(b + j * 2048);
   };
   auto mma = [&](const h8 (&xa)[4], const h8 (&wb)[J]) {
 #pragma unroll
@@ -184,28 +201,52 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   // ---- ring schedule.  Roles at iteration `it`: tile it computes, tile it+1 has LANDED (its first
   // fragments are prefetched while tile it's second half runs), tiles it+2, it+3 are in flight, and
   // the slot of tile it-1 (fully read before this iteration's barrier) is the one being refilled.
-#pragma unroll
-  for (int d = 0; d < 3; ++d)
-    if (d < nk) issue(kt0 + d, d);
-  if (nk >= 3) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tiles 0 and 1 landed (this wave's share)
+  // Every iteration issues exactly LPT DMA loads (dead ones past the end carry zero records), so the
+  // counted wait is a constant and the loop body is ONE basic block the scheduler can interleave.
+  issue();
+  issue();
+  issue();
+  wait_vmcnt<LPT>();   // tiles 0 and 1 landed (this wave's share)
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
   h8 xa0[4], wb0[J], xa1[4], wb1[J];
-  if (nk > 0) read_frags(0, 0, xa0, wb0);
+  read_frags(0, 0, xa0, wb0);
+  int comp_off = 0;
   for (int it = 0; it < nk; ++it) {
     if (it > 0) {
-      if (it + 2 <= nk - 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile it+1 landed
+      wait_vmcnt<LPT>();   // tile it+1 landed (tile it+2's group may still be in flight)
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
     }
-    if (it + 3 < nk) issue(kt0 + it + 3, (it + 3) & 3);
-    read_frags(it & 3, 1, xa1, wb1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int n1 = comp_off + STAGE;
+    const int next_off = n1 >= 4 * STAGE ? 0 : n1;
+    issue();                                  // tile it+3 -> slot of tile it-1
+    read_frags(comp_off, 1, xa1, wb1);
     mma(xa0, wb0);
-    if (it + 1 < nk) read_frags((it + 1) & 3, 0, xa0, wb0);
+    read_frags(next_off, 0, xa0, wb0);        // tile it+1 (harmless garbage after the last tile)
     mma(xa1, wb1);
+    // interleave: first half of the MFMAs carries the DMA issue and the second-half fragment reads,
+    // the second half carries the prefetch of the next tile's fragments
+#pragma unroll
+    for (int g = 0; g < 4 * J; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+      if (g < 4 + J) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
+      if (g < LPT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // 1 VMEM read (DMA)
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                       // 2 VALU
+      __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                       // 3 SALU
+    }
+#pragma unroll
+    for (int g = 0; g < 4 * J; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (g < 4 + J) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+    }
+    comp_off = next_off;
     __builtin_amdgcn_sched_barrier(0);
   }
+  wait_vmcnt<0>();   // drain the dead tail loads before the epilogue's stores
 
   // ---- epilogue (identical to igemm.hip)
   const int g = lane >> 4, mc = lane & 15;
@@ -268,9 +309,9 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 template <int BN>
 constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2; }
 
-template <int BN>
+template <int BN, bool UPS>
 int set_attr() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN, UPS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BN>()));
   return DADD_OK;
 }
@@ -278,8 +319,11 @@ int set_attr() {
 }  // namespace
 
 int dadd_init_igemm_dma() {
-  int rc = set_attr<128>();
-  return rc != DADD_OK ? rc : set_attr<160>();
+  int rc = set_attr<128, false>();
+  if (rc == DADD_OK) rc = set_attr<128, true>();
+  if (rc == DADD_OK) rc = set_attr<160, false>();
+  if (rc == DADD_OK) rc = set_attr<160, true>();
+  return rc;
 }
 
 int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s) {
@@ -289,10 +333,14 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_
   DADD_REQUIRE((size_t)a.B * a.Hi * a.Wi * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2 < 0x7FF00000ull &&
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "igemm(dma): operand larger than the 2 GiB buffer window");
-  if (tile_n == 160)
-    hipLaunchKernelGGL(igemm_dma_kernel<160>, grid, dim3(256), smem_bytes<160>(), s, a);
-  else
-    hipLaunchKernelGGL(igemm_dma_kernel<128>, grid, dim3(256), smem_bytes<128>(), s, a);
+  constexpr int smem160 = smem_bytes<160>(), smem128 = smem_bytes<128>();
+  if (tile_n == 160) {
+    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true>), grid, dim3(256), smem160, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<160, false>), grid, dim3(256), smem160, s, a);
+  } else {
+    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true>), grid, dim3(256), smem128, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<128, false>), grid, dim3(256), smem128, s, a);
+  }
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
