@@ -8,6 +8,7 @@
 
 int dadd_init_igemm();
 int dadd_init_attention();
+int dadd_init_norm();
 
 namespace {
 thread_local char g_err[512] = "";
@@ -55,7 +56,8 @@ int dadd_version(void) { return 100; }
 
 int dadd_init(void) {
   int rc = dadd_init_igemm();
-  return rc != DADD_OK ? rc : dadd_init_attention();
+  if (rc == DADD_OK) rc = dadd_init_attention();
+  return rc != DADD_OK ? rc : dadd_init_norm();
 }
 
 int dadd_device_info(int device, int64_t out[4]) {
@@ -105,7 +107,7 @@ int dadd_graph_destroy(void* graph_exec) {
 }
 
 int dadd_prof_begin(int kind) {
-  DADD_REQUIRE(kind == 1, "prof_begin: unknown kernel family %d", kind);
+  DADD_REQUIRE(kind == 1 || kind == 2, "prof_begin: unknown kernel family %d", kind);
   g_prof.kind = kind;
   g_prof.used = 0;
   g_prof.flop.clear();

@@ -360,8 +360,6 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   DADD_REQUIRE(nsplit == 1 || (a.partial != nullptr && !geglu),
                "igemm: split-K needs a partial buffer and no GEGLU");
 
-  const bool prof = dadd_prof_active(1);
-  if (prof) dadd_prof_pre(s);
   // two K tiles in flight except where that spills (128x160) or when the caller asks for one
   bool deep = (d->flags & DADD_TUNE_SHALLOW) == 0;
   int tile_m = d->tile_m;
@@ -371,6 +369,10 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
   const bool dma = tile_m == 128 && (d->flags & DADD_TUNE_NODMA) == 0;
+  // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false>, the
+  // dominant kernel of the UNet step (one row of a rocprofv3 --stats summary)
+  const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && dma && tile_n == 160 && !a.ups);
+  if (prof) dadd_prof_pre(s);
   if (dma)
     rc = dadd_launch_igemm_dma(a, tile_n, nsplit, s);
   else if (tile_m == 128)

@@ -145,6 +145,61 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
   }
 }
 
+// Single-launch GroupNorm for feature maps whose (batch, group) slab fits LDS (every UNet level
+// below 64x64x640): one block per (group, batch) stages its HW x cg slab in LDS while summing,
+// reduces, then normalises from LDS.  One launch and two HBM passes instead of two launches and
+// three passes; the slab rows are cg*2 bytes (20..160 B) so the accesses are 4-byte pairs, which
+// is fine for tensors that live in L2.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  h2* slab = reinterpret_cast<h2*>(smraw);                 // [HW][cg/2]
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int hp = p.cg >> 1;                                // channel pairs per row of the slab
+  const int c0 = g * p.cg;
+  const int npair = p.HW * hp;
+  float s = 0.f, ss = 0.f;
+  for (int idx = t; idx < npair; idx += 256) {
+    const int row = idx / hp, cp = idx - row * hp;
+    const int c = c0 + 2 * cp;
+    const size_t pix = (size_t)b * p.HW + row;
+    const h2 v = (c < p.C1) ? *reinterpret_cast<const h2*>(p.x1 + pix * p.C1 + c)
+                            : *reinterpret_cast<const h2*>(p.x2 + pix * p.C2 + (c - p.C1));
+    slab[idx] = v;
+    const float a = (float)v[0], d = (float)v[1];
+    s += a + d;
+    ss += a * a + d * d;
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+  __syncthreads();
+  const double n = (double)p.HW * (double)p.cg;
+  const double sum = (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3];
+  const double sq = (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3];
+  const double mu = sum / n;
+  double var = sq / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  for (int idx = t; idx < npair; idx += 256) {
+    const int row = idx / hp, cp = idx - row * hp;
+    const int c = c0 + 2 * cp;
+    const h2 v = slab[idx];
+    h2 o;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float sc = rstd * p.gamma[c + e];
+      float f = ((float)v[e] - mean) * sc + p.beta[c + e];
+      if (p.silu) f = dadd_silu(f);
+      o[e] = (half_t)f;
+    }
+    *reinterpret_cast<h2*>(p.out + ((size_t)b * p.HW + row) * p.C + c) = o;
+  }
+}
+
+constexpr int GN_FUSED_MAX_BYTES = 16 * 1024;   // measured: wins only below ~16 KiB per (batch, group) slab
+
 // LayerNorm: one wave per row, the row lives in registers (exact two-pass variance).
 constexpr int LN_MAXV = 4;  // C <= 8*64*4 = 2048
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x,
@@ -203,6 +258,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 
 }  // namespace
 
+int dadd_init_norm() {
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GN_FUSED_MAX_BYTES));
+  return DADD_OK;
+}
+
 extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
                                   const float* gamma, const float* beta, void* out, float* ws,
                                   int B, int HW, int groups, float eps, int silu, void* stream) {
@@ -236,6 +297,12 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   p.rows_per_block = 4 * p.RP;
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t slab_bytes = (size_t)HW * p.cg * sizeof(half_t);
+  if (slab_bytes <= (size_t)GN_FUSED_MAX_BYTES && p.cg % 2 == 0 && C1 % 2 == 0) {
+    hipLaunchKernelGGL(gn_fused_kernel, dim3(groups, B), dim3(256), slab_bytes, s, p);
+    DADD_LAUNCH_CHECK();
+    return DADD_OK;
+  }
   const size_t sm1 = (size_t)2 * p.RP * C * sizeof(float);
   const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, B), dim3(256), sm1, s, p);

@@ -146,7 +146,9 @@ def test_igemm_rejects_bad_contract(hip):
 
 @pytest.mark.parametrize("c1,c2,hw,silu,eps", [(320, 0, 256, 1, 1e-5), (1280, 640, 64, 1, 1e-5),
                                                (640, 320, 100, 0, 1e-6), (128, 0, 4096, 1, 1e-6),
-                                               (1280, 1280, 16, 1, 1e-5)])
+                                               (1280, 1280, 16, 1, 1e-5),
+                                               (320, 320, 4096, 1, 1e-5),      # slab > LDS: two-pass path
+                                               (640, 320, 4096, 0, 1e-6), (128, 0, 16384, 1, 1e-6)])
 def test_groupnorm(hip, c1, c2, hw, silu, eps):
     b, side = 2, int(math.isqrt(hw))
     x1 = rnd((b, side, side, c1), 22, 1.5) + 0.3
