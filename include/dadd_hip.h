@@ -60,7 +60,8 @@ int dadd_device_info(int device, int64_t out[4]);
  * reference calls at src/models/unet/unet.py:140-144, src/models/vae/vae.py:88,112 and
  * src/models/attention_processor_routing_gates.py:123,133-137,161-162,183.
  * Contract: (C1+C2) % 64 == 0, C1 % 64 == 0, N % 8 == 0, 16-byte aligned pointers.
- * splitk > 1 needs `partial` (fp32, splitk*M*N) and is finished by the same call. */
+ * splitk > 1 needs `partial` (fp32, splitk*M*N); the slabs are combined by the last-arriving slice of
+ * each tile when `counters` is given, else by a finish kernel launched by the same call. */
 typedef struct {
   const void* x;
   const void* x2;
@@ -75,6 +76,8 @@ typedef struct {
   int32_t ldo, ldr, ld_rowvec;
   int32_t splitk, flags, tile_n; /* tile_n: 128 or 160 (0 = choose) */
   int32_t tile_m;                /* 64 or 128 (0 = 128): rows of the output tile */
+  int32_t* counters;             /* split-K tickets: >= #output tiles ints, zero between launches; with
+                                    them the slabs are combined inside the launch (NULL: finish kernel) */
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 

@@ -49,19 +49,46 @@ struct FlashArgs {
   float scale_log2;  // log2(e)/sqrt(d)
 };
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h8 pack_p8(const f4& lo, const f4& hi) {   // 8 floats -> 8 halfs, pairwise
+  const h2 a = __builtin_convertvector((f2v){lo[0], lo[1]}, h2);
+  const h2 b = __builtin_convertvector((f2v){lo[2], lo[3]}, h2);
+  const h2 c = __builtin_convertvector((f2v){hi[0], hi[1]}, h2);
+  const h2 d = __builtin_convertvector((f2v){hi[2], hi[3]}, h2);
+  h8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+  r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
+  return r;
+}
+
+// K tile image in LDS: KP panels of [64 keys][64 halfs], the igemm XOR swizzle inside a panel
+// (measured conflict-free for the 16-row ds_read_b128 fragment reads).
+__device__ __forceinline__ int kpanel_off(int row, int chunk) {
+  return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8;
+}
+
 // DR = real head dim. Block = 4 waves x (16*QF) queries; KV tile = 64 keys.
+//
+// VALU is the bound of this kernel (PMC: VALU issue 73 % of the time, MFMA 23 %), so the inner loop
+// is built to minimise vector instructions: all tile addressing is hoisted out of the loop, scores
+// stay unscaled in the accumulator with the scale fused into the exponent (one fma + one v_exp_f32
+// per score), the mask runs only on a ragged last tile, O is rescaled only when a row maximum moved,
+// probabilities are converted pairwise, and — when the head dim leaves a spare column in its
+// 16-multiple (d = 40 -> 48) — a column of ones in V makes the PV MFMA produce the softmax row sums.
 template <int DR, int QF, bool PREFETCH>
 __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int KS = D / 32, DF = DVP / 16, DC = DR / 8;
-  constexpr int KLD = D + 8, VLD = v_stride(DVP);
+  constexpr int KP = (D + 63) / 64, KTILE = KP * 64 * 64;       // halfs
+  constexpr int VLD = v_stride(DVP), VTILE = 64 * VLD;
+  constexpr int TILE_HALFS = KTILE + VTILE;
   constexpr int NL = (64 * DC + 255) / 256;  // 16-byte loads per thread per tile per tensor
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // PREFETCH variants double-buffer the K/V tiles (one barrier per tile); buffer b at KsB(b)/VsB(b)
+  constexpr bool SUMCOL = DVP > DR;          // spare V column available for the row sums
   constexpr int NBUFS = PREFETCH ? 2 : 1;
-  constexpr int TILE_HALFS = 64 * (KLD + VLD);
-  half_t* Ks = reinterpret_cast<half_t*>(smem);
-  half_t* Vs = Ks + 64 * KLD;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* Ks = reinterpret_cast<half_t*>(smem);   // buffer b: K at Ks + b*TILE_HALFS, V right after
+  half_t* Vs = Ks + KTILE;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
@@ -69,8 +96,11 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   const size_t tok0 = (size_t)b * p.N;
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // zero the padding columns once (K: [DR,D), V: [DR,DVP)); tile stores never touch them
+  // zero both buffers once (padding columns are never written again); ones column for the row sums
   for (int i = t; i < NBUFS * TILE_HALFS / 8; i += 256) *reinterpret_cast<h8*>(Ks + i * 8) = zero8;
+  __syncthreads();
+  if (SUMCOL)
+    for (int i = t; i < NBUFS * 64; i += 256) Vs[(i >> 6) * TILE_HALFS + (i & 63) * VLD + DR] = (half_t)1.0f;
 
   // Q fragments (B operand of S^T = K Q^T): lane -> query li, d-chunk 32s + 8g
   h8 qf[QF][KS];
@@ -96,49 +126,65 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
     for (int df = 0; df < DF; ++df) oacc[df][f] = f4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // hoisted tile addressing: what this thread loads / stores for every tile
+  int g_off[NL], k_lds[NL], v_lds[NL], t_row[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int idx = t + 256 * u;
+    const int row = idx / DC, ch = idx - row * DC;
+    t_row[u] = (idx < 64 * DC) ? row : 1 << 30;      // rows past the tile never pass the key test
+    g_off[u] = row * p.ld + h * DR + ch * 8;
+    k_lds[u] = (ch >> 3) * 4096 + kpanel_off(row, ch & 7);
+    v_lds[u] = row * VLD + ch * 8;
+  }
+  const half_t* kbase = p.k + tok0 * p.ld;
+  const half_t* vbase = p.v + tok0 * p.ld;
+  // fragment read addresses (lane-constant): K row li of panel-half sp, V tr-read block of lane
+  int ka_off[2];
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp) ka_off[sp] = kpanel_off(li, sp * 4 + g);
+  const int va_off = (4 * g + (li >> 2)) * VLD + 4 * (li & 3);
+
   const int nkt = (p.N + 63) / 64;
   h8 rk[PREFETCH ? NL : 1], rv[PREFETCH ? NL : 1];
-
-  auto tile_load = [&](int kt) {
-#pragma unroll
+  auto tile_direct = [&](int kt) {   // large head dims: no register staging across the compute phase
+    const size_t toff = (size_t)kt * 64 * p.ld;
+    const int kmax = p.N - kt * 64;
+#pragma unroll 4
     for (int u = 0; u < NL; ++u) {
-      const int idx = t + 256 * u;
-      const int row = idx / DC, ch = idx - row * DC;
-      const int key = kt * 64 + row;
-      const bool ok = (idx < 64 * DC) & (key < p.N);
-      const size_t off = (tok0 + key) * p.ld + h * DR + ch * 8;
-      rk[u] = ok ? *reinterpret_cast<const h8*>(p.k + off) : zero8;
-      rv[u] = ok ? *reinterpret_cast<const h8*>(p.v + off) : zero8;
-    }
-  };
-  auto tile_store = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < NL; ++u) {
-      const int idx = t + 256 * u;
-      const int row = idx / DC, ch = idx - row * DC;
-      if (idx < 64 * DC) {
-        *reinterpret_cast<h8*>(Ks + buf * TILE_HALFS + row * KLD + ch * 8) = rk[u];
-        *reinterpret_cast<h8*>(Vs + buf * TILE_HALFS + row * VLD + ch * 8) = rv[u];
+      if (t_row[u] < 64) {
+        const bool ok = t_row[u] < kmax;
+        *reinterpret_cast<h8*>(Ks + k_lds[u]) = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
+        *reinterpret_cast<h8*>(Vs + v_lds[u]) = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
       }
     }
   };
-  auto tile_direct = [&](int kt) {  // no register staging across the compute phase (large DR)
-    for (int idx = t; idx < 64 * DC; idx += 256) {
-      const int row = idx / DC, ch = idx - row * DC;
-      const int key = kt * 64 + row;
-      const size_t off = (tok0 + key) * p.ld + h * DR + ch * 8;
-      const bool ok = key < p.N;
-      *reinterpret_cast<h8*>(Ks + row * KLD + ch * 8) =
-          ok ? *reinterpret_cast<const h8*>(p.k + off) : zero8;
-      *reinterpret_cast<h8*>(Vs + row * VLD + ch * 8) =
-          ok ? *reinterpret_cast<const h8*>(p.v + off) : zero8;
+  auto tile_load = [&](int kt) {
+    const size_t toff = (size_t)kt * 64 * p.ld;
+    const int kmax = p.N - kt * 64;                  // rows < kmax are real keys
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const bool ok = t_row[u] < kmax;
+      rk[u] = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
+      rv[u] = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
+    }
+  };
+  auto tile_store = [&](int buf) {
+    half_t* kd = Ks + buf * TILE_HALFS;
+    half_t* vd = Vs + buf * TILE_HALFS;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      if (t_row[u] < 64) {
+        *reinterpret_cast<h8*>(kd + k_lds[u]) = rk[u];
+        *reinterpret_cast<h8*>(vd + v_lds[u]) = rv[u];
+      }
     }
   };
 
   const bool ragged = (p.N & 63) != 0;
   if (PREFETCH) {
     tile_load(0);
-    __syncthreads();   // zero fill done
+    __syncthreads();   // ones column / zero fill done
     tile_store(0);
   }
   for (int kt = 0; kt < nkt; ++kt) {
@@ -162,35 +208,34 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
       for (int f = 0; f < QF; ++f) sacc[kf][f] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+      const half_t* kp = Kc + (s >> 1) * 4096 + ka_off[s & 1];
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf) {
-        const h8 ka = *reinterpret_cast<const h8*>(Kc + (kf * 16 + li) * KLD + 32 * s + 8 * g);
+        const h8 ka = *reinterpret_cast<const h8*>(kp + kf * 1024);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
           sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], sacc[kf][f], 0, 0, 0);
       }
     }
 
-    // ---- online softmax per query column.  Scores stay unscaled in the accumulator; the scale is
-    // fused into the exponent (one fma + one v_exp_f32 per score).  The key mask runs only on a
-    // ragged last tile, and O is rescaled only when some row maximum actually moved.
+    // ---- online softmax per query column
     h8 pb[QF][2];
-    const int kbase = kt * 64 + 4 * g;
-    const bool mask_tile = ragged && (kt == nkt - 1);
+    if (ragged && kt == nkt - 1) {
+      const int kbase_i = kt * 64 + 4 * g;
 #pragma unroll
-    for (int f = 0; f < QF; ++f) {
-      if (mask_tile) {
+      for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kbase + kf * 16 + r >= p.N) sacc[kf][f][r] = -3.0e38f;
-      }
-      float mx = -3.0e38f;
+            if (kbase_i + kf * 16 + r >= p.N) sacc[kf][f][r] = -3.0e38f;
+    }
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+    for (int f = 0; f < QF; ++f) {
+      float mx = fmaxf(fmaxf(sacc[0][f][0], sacc[0][f][1]), fmaxf(sacc[0][f][2], sacc[0][f][3]));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kf][f][r]);
+      for (int kf = 1; kf < 4; ++kf)
+        mx = fmaxf(fmaxf(fmaxf(mx, sacc[kf][f][0]), sacc[kf][f][1]), fmaxf(sacc[kf][f][2], sacc[kf][f][3]));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrow[f], mx * p.scale_log2);      // running max in log2 units
@@ -202,28 +247,30 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
         for (int r = 0; r < 4; ++r) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][r], p.scale_log2, -mnew));
           sacc[kf][f][r] = pv;
-          rs += pv;
+          if (!SUMCOL) rs += pv;
         }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
       if (__any(moved)) {                                        // wave-uniform branch
         const float alpha = __builtin_amdgcn_exp2f(mrow[f] - mnew);
-        lrow[f] *= alpha;
+        if (!SUMCOL) lrow[f] *= alpha;
 #pragma unroll
         for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
       }
-      lrow[f] += rs;
+      if (!SUMCOL) {
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        lrow[f] += rs;
+      }
       mrow[f] = mnew;
-      pb[f][0] = pack_p(sacc[0][f], sacc[1][f]);
-      pb[f][1] = pack_p(sacc[2][f], sacc[3][f]);
+      pb[f][0] = pack_p8(sacc[0][f], sacc[1][f]);
+      pb[f][1] = pack_p8(sacc[2][f], sacc[3][f]);
     }
 
-    // ---- O^T += V^T P^T
+    // ---- O^T += V^T P^T   (with SUMCOL, row DR of O^T accumulates sum_k P = the softmax denominator)
 #pragma unroll
     for (int df = 0; df < DF; ++df) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const half_t* base = Vc + (kb * 32 + 4 * g + (li >> 2)) * VLD + df * 16 + 4 * (li & 3);
+        const half_t* base = Vc + va_off + kb * 32 * VLD + df * 16;
         const h8 va = tr_pair(base, base + 16 * VLD);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
@@ -236,9 +283,13 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   // ---- normalise and store: lane owns O[q = li][d = df*16 + 4g .. +3]
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
+    float l = lrow[f];
+    if (SUMCOL) {   // row DR of O^T: fragment DR/16, lane group (DR%16)/4, register DR%4
+      l = __shfl(oacc[DR / 16][f][DR % 4], ((DR % 16) / 4) * 16 + li, 64);
+    }
     const int qrow = qw0 + f * 16 + li;
     if (qrow >= p.N) continue;
-    const float inv = 1.0f / lrow[f];
+    const float inv = 1.0f / l;
     half_t* op = p.out + (tok0 + qrow) * p.ldo + h * DR;
 #pragma unroll
     for (int df = 0; df < DF; ++df) {
@@ -414,7 +465,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
 template <int DR, int QF, bool PF>
 int flash_attr() {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
-  constexpr int smem = (PF ? 2 : 1) * 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
+  constexpr int smem = (PF ? 2 : 1) * (((D + 63) / 64) * 4096 + 64 * v_stride(DVP)) * (int)sizeof(half_t);
   DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<DR, QF, PF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
@@ -423,7 +474,7 @@ int flash_attr() {
 template <int DR, int QF, bool PF>
 int launch_flash(const FlashArgs& a, hipStream_t s) {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
-  constexpr int smem = (PF ? 2 : 1) * 64 * ((D + 8) + v_stride(DVP)) * (int)sizeof(half_t);
+  constexpr int smem = (PF ? 2 : 1) * (((D + 63) / 64) * 4096 + 64 * v_stride(DVP)) * (int)sizeof(half_t);
   dim3 grid((a.N + 64 * QF - 1) / (64 * QF), a.B * a.H);
   hipLaunchKernelGGL((flash_kernel<DR, QF, PF>), grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();

@@ -15,6 +15,7 @@
 // skip-connection concat are all folded into the A-tile address generation.
 #include "dadd_common.h"
 #include "igemm_args.h"
+#include "igemm_epilogue.h"
 
 namespace {
 
@@ -177,62 +178,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane holds out[m][n .. n+3] for (i, j); m = column of the swapped MFMA result
-  const int g = lane >> 4, mc = lane & 15;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * WM + i * 16 + mc;
-    if (m >= p.M) continue;
-    const int b = m / HoWo;
-    if (p.splitk > 1) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int n = n0 + wn * WN + j * 16 + g * 4;
-        if (n < p.N)
-          *reinterpret_cast<f4*>(p.partial + ((size_t)z * p.M + m) * p.N + n) = acc[j][i];
-      }
-      continue;
-    }
-    if (p.flags & DADD_EPI_GEGLU) {
-      if constexpr (J == 4) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int nh = n0 + wn * WN + j * 16 + g * 4;  // physical (interleaved) weight rows
-          const int ng = nh + 32;
-          if (ng >= p.N) continue;
-          f4 hv = acc[j][i], gv = acc[j + 2][i];
-          if (p.flags & DADD_EPI_BIAS) {
-            hv += *reinterpret_cast<const f4*>(p.bias + nh);
-            gv += *reinterpret_cast<const f4*>(p.bias + ng);
-          }
-          const int no = (n0 >> 1) + wn * 32 + j * 16 + g * 4;
-          h4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(hv[r] * dadd_gelu(gv[r]));
-          *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + no) = o;
-        }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int n = n0 + wn * WN + j * 16 + g * 4;
-      if (n >= p.N) continue;
-      f4 v = acc[j][i];
-      if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
-      if (p.flags & DADD_EPI_ROWVEC)
-        v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);
-      if (p.flags & DADD_EPI_RESIDUAL) {
-        const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-      }
-      h4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-      *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
-    }
-  }
+  // ---- epilogue (shared with igemm_dma.hip): lane holds out[m][n .. n+3] of the swapped MFMA result
+  igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
 }
 
 // Finishes a split-K launch: sums the fp32 slabs and applies the (non-GEGLU) epilogue.
@@ -311,6 +258,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.bias = d->bias;
   a.rowvec = d->rowvec;
   a.residual = static_cast<const half_t*>(d->residual);
+  a.counters = d->counters;
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
@@ -381,7 +329,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     rc = (tile_n == 160) ? launch2<64, 160>(a, nsplit, deep, s) : launch2<64, 128>(a, nsplit, deep, s);
   if (prof) dadd_prof_post(s, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (rc != DADD_OK) return rc;
-  if (nsplit > 1) {
+  if (nsplit > 1 && a.counters == nullptr) {
     const size_t total = (size_t)a.M * (a.N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

@@ -11,6 +11,7 @@ struct IgemmArgs {
   const float* bias;
   const float* rowvec;
   const half_t* residual;
+  int* counters;   // split-K tickets, one per output tile, zero between launches (nullptr: finish kernel)
   int B, Hi, Wi, C1, C2, Ho, Wo, N;
   int taps, stride, ups, pad;
   int ldo, ldr, ld_rowvec;

@@ -17,6 +17,7 @@
 // against 36.8 KB per K tile); LDS-DMA removes that traffic from the VGPR->LDS path entirely.
 #include "dadd_common.h"
 #include "igemm_args.h"
+#include "igemm_epilogue.h"
 
 namespace {
 
@@ -248,61 +249,8 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   }
   wait_vmcnt<0>();   // drain the dead tail loads before the epilogue's stores
 
-  // ---- epilogue (identical to igemm.hip)
-  const int g = lane >> 4, mc = lane & 15;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + mc;
-    if (m >= p.M) continue;
-    const int b = m / HoWo;
-    if (p.splitk > 1) {
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int n = n0 + wn * WN + j * 16 + g * 4;
-        if (n < p.N) *reinterpret_cast<f4*>(p.partial + ((size_t)z * p.M + m) * p.N + n) = acc[j][i];
-      }
-      continue;
-    }
-    if (p.flags & DADD_EPI_GEGLU) {
-      if constexpr (J == 4) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int nh = n0 + wn * WN + j * 16 + g * 4;
-          const int ng = nh + 32;
-          if (ng >= p.N) continue;
-          f4 hv = acc[j][i], gv = acc[j + 2][i];
-          if (p.flags & DADD_EPI_BIAS) {
-            hv += *reinterpret_cast<const f4*>(p.bias + nh);
-            gv += *reinterpret_cast<const f4*>(p.bias + ng);
-          }
-          const int no = (n0 >> 1) + wn * 32 + j * 16 + g * 4;
-          h4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(hv[r] * dadd_gelu(gv[r]));
-          *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + no) = o;
-        }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int n = n0 + wn * WN + j * 16 + g * 4;
-      if (n >= p.N) continue;
-      f4 v = acc[j][i];
-      if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
-      if (p.flags & DADD_EPI_ROWVEC)
-        v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);
-      if (p.flags & DADD_EPI_RESIDUAL) {
-        const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-      }
-      h4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-      *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
-    }
-  }
+  // ---- epilogue (shared with igemm.hip)
+  igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
 #endif
 }
 

@@ -1,0 +1,109 @@
+// Epilogue shared by the two implicit-GEMM kernels: bias / time-embedding row / residual / GEGLU,
+// fp16 stores of 4 consecutive channels per lane, and the split-K combine.
+//
+// Split-K.  Every K slice writes its fp32 slab; with `counters` the combine happens IN the launch:
+// the slice that draws the last ticket of a tile re-reads all slabs in slice order (so the sum is
+// bit-reproducible) and runs the epilogue.  The hand-off follows cdna_hip_programming.md §6
+// Guideline 16 in its counter form: plain slab stores -> every wave s_waitcnt vmcnt(0) -> barrier ->
+// one lane: agent-scope release fence, asm vmcnt(0), relaxed agent fetch_add; the last arriver does
+// one agent-scope acquire, asm vmcnt(0), resets the ticket for the next launch, and a barrier
+// releases the other waves to plain loads.  No spinning, no residency assumption, results do not
+// depend on block placement.  Without `counters` a separate finish kernel combines the slabs.
+#pragma once
+#include "igemm_args.h"
+
+template <int J, int MI, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][MI], int m0, int n0,
+                                               int wm, int wn, int lane, int z, char* smem) {
+  const int g = lane >> 4, mc = lane & 15;
+  const int HoWo = p.Ho * p.Wo;
+  if (p.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WM + i * 16 + mc;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        if (n < p.N) *reinterpret_cast<f4*>(p.partial + ((size_t)z * p.M + m) * p.N + n) = acc[j][i];
+      }
+    }
+    if (p.counters == nullptr) return;   // combined by splitk_finish_kernel
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                     // every wave's slab stores are issued and drained; LDS is free
+    volatile int* flag = reinterpret_cast<volatile int*>(smem);
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int* ticket = p.counters + blockIdx.x;
+      const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (prev == p.splitk - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WM + i * 16 + mc;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n < p.N)
+          for (int s = 0; s < p.splitk; ++s)
+            v += *reinterpret_cast<const f4*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
+        acc[j][i] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WM + i * 16 + mc;
+    if (m >= p.M) continue;
+    const int b = m / HoWo;
+    if (p.flags & DADD_EPI_GEGLU) {
+      if constexpr (J == 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int nh = n0 + wn * WN + j * 16 + g * 4;  // physical (interleaved) weight rows
+          const int ng = nh + 32;
+          if (ng >= p.N) continue;
+          f4 hv = acc[j][i], gv = acc[j + 2][i];
+          if (p.flags & DADD_EPI_BIAS) {
+            hv += *reinterpret_cast<const f4*>(p.bias + nh);
+            gv += *reinterpret_cast<const f4*>(p.bias + ng);
+          }
+          const int no = (n0 >> 1) + wn * 32 + j * 16 + g * 4;
+          h4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(hv[r] * dadd_gelu(gv[r]));
+          *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + no) = o;
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = n0 + wn * WN + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      f4 v = acc[j][i];
+      if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
+      if (p.flags & DADD_EPI_ROWVEC)
+        v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);
+      if (p.flags & DADD_EPI_RESIDUAL) {
+        const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      h4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+      *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
+    }
+  }
+}

@@ -123,6 +123,11 @@ class _Plan:
         self.ops: List = []
         self.keep: List[torch.Tensor] = []  # weights & persistent buffers
         self.gn_ws = None
+        # Split-K slabs are combined by the finish kernel.  The in-launch combine (last-arriving slice
+        # reduces; `counters` of dadd_conv_igemm_f16) is implemented and tested but measured 2-4x SLOWER
+        # on MI355X for these shapes (M=256 N=1280 K=11520, 16 slices: 122 us vs 27 us): every slice
+        # pays an agent-scope release (L2 write-back) — cdna_hip_programming.md "cut GEMM->GEMM seams".
+        self.sk_counters = None
 
     def rec(self, fn, *a, **k):
         self.ops.append((fn, a, k))
@@ -149,7 +154,7 @@ class _Plan:
             | (L.EPI_RESIDUAL if residual is not None else 0) | tune
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
                  taps=taps, stride=stride, ups=ups, pad=pad, flags=f, splitk=sk, partial=partial,
-                 tile_n=tile_n, tile_m=tile_m)
+                 tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None)  # None: finish kernel
         self.pool.put(partial)
         return out
 

@@ -28,7 +28,7 @@ class IgemmDesc(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "x2", "w", "out", "partial", "bias", "rowvec", "residual")] + \
                [(n, i32) for n in ("B", "Hi", "Wi", "C1", "C2", "Ho", "Wo", "N", "taps", "stride",
                                    "ups", "pad", "ldo", "ldr", "ld_rowvec", "splitk", "flags",
-                                   "tile_n", "tile_m")]
+                                   "tile_n", "tile_m")] + [("counters", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/dadd_hip.h declares

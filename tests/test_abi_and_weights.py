@@ -34,8 +34,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_igemm_desc_layout_matches_header():
-    # 8 pointers + 19 int32 = 64 + 76 bytes, padded to the pointer alignment
-    assert ctypes.sizeof(L.IgemmDesc) == 144
+    # 8 pointers + 19 int32 (+4 pad) + 1 pointer
+    assert ctypes.sizeof(L.IgemmDesc) == 152
     assert [f[0] for f in L.IgemmDesc._fields_][:8] == ["x", "x2", "w", "out", "partial", "bias", "rowvec", "residual"]
 
 

@@ -44,15 +44,21 @@ def close(got, ref, atol, rtol, what=""):
 
 def run_igemm(hip, x, w, out_shape, **kw):
     tens = {k: kw.pop(k, None) for k in ("x2", "bias", "rowvec", "residual")}
+    in_launch = kw.pop("in_launch_combine", True)     # split-K slabs combined by the last arriver
+    repeats = kw.pop("repeats", 1)
     splitk = kw.get("splitk", 1)
     o_ref = torch.zeros(out_shape, dtype=F16)
     REF.igemm(x, w, o_ref, **tens, **kw)
     o = hip.zeros(out_shape, F16)
     m = out_shape[0] * out_shape[1] * out_shape[2]
     partial = hip.zeros((splitk * m * w.shape[0],), F32) if splitk > 1 else None
-    hip.igemm(dev(hip, x), dev(hip, w), o, **{k: dev(hip, v) for k, v in tens.items()},
-              partial=partial, **kw)
+    counters = hip.zeros((4096,), torch.int32) if (splitk > 1 and in_launch) else None
+    xd, wd, td = dev(hip, x), dev(hip, w), {k: dev(hip, v) for k, v in tens.items()}
+    for _ in range(repeats):      # >1: the tickets must be back at zero after every launch
+        hip.igemm(xd, wd, o, **td, partial=partial, counters=counters, **kw)
     hip.synchronize()
+    if counters is not None:
+        assert int(counters.abs().sum().item()) == 0, "split-K tickets not reset"
     return o, o_ref
 
 
@@ -89,14 +95,21 @@ def test_igemm_skip_concat(hip, taps):
     close(o, o_ref, 3e-3, 2e-3, f"concat taps{taps}")
 
 
+@pytest.mark.parametrize("in_launch", [True, False])
 @pytest.mark.parametrize("splitk", [2, 7, 16])
-def test_igemm_splitk_matches_single_pass(hip, splitk):
-    b, h, c, n = 1, 8, 1280, 1280
+def test_igemm_splitk_matches_single_pass(hip, splitk, in_launch):
+    """K slices combined inside the launch by the last-arriving slice (agent-scope ticket) or by the
+    separate finish kernel; three back-to-back launches reuse the tickets; both orders of summation are
+    fixed, so the two modes must agree bit for bit."""
+    b, h, c, n = 2, 16, 1280, 1280
     x, w = rnd((b, h, h, c), 13), rnd((n, 9 * c), 14, 1 / math.sqrt(9 * c))
     bias, res = rnd((n,), 15, 0.1, F32), rnd((b, h, h, n), 16)
     o, o_ref = run_igemm(hip, x, w, (b, h, h, n), bias=bias, residual=res, taps=9, pad=1, flags=5,
-                         splitk=splitk)
-    close(o, o_ref, 3e-3, 2e-3, f"splitk {splitk}")
+                         splitk=splitk, in_launch_combine=in_launch, repeats=3)
+    close(o, o_ref, 3e-3, 2e-3, f"splitk {splitk} in_launch={in_launch}")
+    o2, _ = run_igemm(hip, x, w, (b, h, h, n), bias=bias, residual=res, taps=9, pad=1, flags=5,
+                      splitk=splitk, in_launch_combine=not in_launch)
+    assert torch.equal(o.cpu(), o2.cpu())
 
 
 @pytest.mark.parametrize("tile_m,tune,splitk", [(128, 0, 1), (128, 0, 3), (128, 32, 1), (128, 32 | 16, 1),

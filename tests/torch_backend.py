@@ -89,7 +89,7 @@ class TorchRefBackend:
         out.copy_(y)
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
-              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0):
+              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None):
         self.launches += 1
         xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
         b, hi, wi, cin = xin.shape
