@@ -12,6 +12,8 @@
 //  * xattn_kernel   : the DADD cross-attention — 2 or 3 sixteen-key pathways with INDEPENDENT
 //                     softmaxes, gate/lambda folded into the probabilities, K/V fragments resident
 //                     in registers for the whole block (they are step-invariant and tiny)
+#include <stdlib.h>
+
 #include "dadd_common.h"
 
 namespace {
@@ -78,6 +80,7 @@ __device__ __forceinline__ int kpanel_off(int row, int chunk) {
 // 16-multiple (d = 40 -> 48) — a column of ones in V makes the PV MFMA produce the softmax row sums.
 template <int DR, int QF, bool PREFETCH>
 __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
+  constexpr bool DEEP = PREFETCH && DR <= 40;   // two tiles in flight where the registers allow it
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int KS = D / 32, DF = DVP / 16, DC = DR / 8;
   constexpr int KP = (D + 63) / 64, KTILE = KP * 64 * 64;       // halfs
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   const int va_off = (4 * g + (li >> 2)) * VLD + 4 * (li & 3);
 
   const int nkt = (p.N + 63) / 64;
-  h8 rk[PREFETCH ? NL : 1], rv[PREFETCH ? NL : 1];
+  h8 rk0[PREFETCH ? NL : 1], rv0[PREFETCH ? NL : 1], rk1[PREFETCH ? NL : 1], rv1[PREFETCH ? NL : 1];
+  (void)rk1; (void)rv1;
   auto tile_direct = [&](int kt) {   // large head dims: no register staging across the compute phase
     const size_t toff = (size_t)kt * 64 * p.ld;
     const int kmax = p.N - kt * 64;
@@ -159,21 +163,21 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
       }
     }
   };
-  auto tile_load = [&](int kt) {
+  auto tile_load = [&](int kt, h8 (&rk)[PREFETCH ? NL : 1], h8 (&rv)[PREFETCH ? NL : 1]) {
     const size_t toff = (size_t)kt * 64 * p.ld;
     const int kmax = p.N - kt * 64;                  // rows < kmax are real keys
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
+    for (int u = 0; u < (PREFETCH ? NL : 1); ++u) {
       const bool ok = t_row[u] < kmax;
       rk[u] = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
       rv[u] = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
     }
   };
-  auto tile_store = [&](int buf) {
+  auto tile_store = [&](int buf, const h8 (&rk)[PREFETCH ? NL : 1], const h8 (&rv)[PREFETCH ? NL : 1]) {
     half_t* kd = Ks + buf * TILE_HALFS;
     half_t* vd = Vs + buf * TILE_HALFS;
 #pragma unroll
-    for (int u = 0; u < NL; ++u) {
+    for (int u = 0; u < (PREFETCH ? NL : 1); ++u) {
       if (t_row[u] < 64) {
         *reinterpret_cast<h8*>(kd + k_lds[u]) = rk[u];
         *reinterpret_cast<h8*>(vd + v_lds[u]) = rv[u];
@@ -182,24 +186,9 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   };
 
   const bool ragged = (p.N & 63) != 0;
-  if (PREFETCH) {
-    tile_load(0);
-    __syncthreads();   // ones column / zero fill done
-    tile_store(0);
-  }
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = PREFETCH ? (kt & 1) : 0;
+  auto compute = [&](int kt, int buf) {
     const half_t* Kc = Ks + buf * TILE_HALFS;
     const half_t* Vc = Vs + buf * TILE_HALFS;
-    if (PREFETCH) {
-      __syncthreads();   // tile kt visible; everyone finished reading tile kt-1 (the other buffer)
-      if (kt + 1 < nkt) tile_load(kt + 1);
-    } else {
-      __syncthreads();
-      tile_direct(kt);
-      __syncthreads();
-    }
-
     // ---- S^T = K Q^T : sacc[kf][f], rows = keys kf*16 + 4g + r, column = query li
     f4 sacc[4][QF];
 #pragma unroll
@@ -277,7 +266,46 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
           oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[f][kb], oacc[df][f], 0, 0, 0);
       }
     }
-    if (PREFETCH && kt + 1 < nkt) tile_store(buf ^ 1);   // last read of that buffer was tile kt-1
+  };
+
+  if (DEEP) {
+    // two tiles in flight: registers set 0 carries even tiles, set 1 odd tiles; LDS buffer = parity.
+    // A load issued at iteration kt is stored at iteration kt+1 (after that tile's compute), i.e. it
+    // has a whole compute phase plus a barrier to land.
+    tile_load(0, rk0, rv0);
+    __syncthreads();   // ones column / zero fill done
+    tile_store(0, rk0, rv0);
+    if (nkt > 1) tile_load(1, rk1, rv1);
+    int kt = 0;
+    while (kt < nkt) {
+      __syncthreads();   // tile kt visible in buffer 0; everyone finished reading tile kt-1 (buffer 1)
+      if (kt + 2 < nkt) tile_load(kt + 2, rk0, rv0);
+      compute(kt, 0);
+      if (kt + 1 < nkt) tile_store(1, rk1, rv1);
+      if (++kt >= nkt) break;
+      __syncthreads();
+      if (kt + 2 < nkt) tile_load(kt + 2, rk1, rv1);
+      compute(kt, 1);
+      if (kt + 1 < nkt) tile_store(0, rk0, rv0);
+      ++kt;
+    }
+  } else if (PREFETCH) {
+    tile_load(0, rk0, rv0);
+    __syncthreads();
+    tile_store(0, rk0, rv0);
+    for (int kt = 0; kt < nkt; ++kt) {
+      __syncthreads();   // tile kt visible; everyone finished reading tile kt-1 (the other buffer)
+      if (kt + 1 < nkt) tile_load(kt + 1, rk0, rv0);
+      compute(kt, kt & 1);
+      if (kt + 1 < nkt) tile_store((kt + 1) & 1, rk0, rv0);
+    }
+  } else {
+    for (int kt = 0; kt < nkt; ++kt) {
+      __syncthreads();
+      tile_direct(kt);
+      __syncthreads();
+      compute(kt, 0);
+    }
   }
 
   // ---- normalise and store: lane owns O[q = li][d = df*16 + 4g .. +3]
@@ -498,6 +526,7 @@ int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
 
 int dadd_init_attention() {
   int rc = flash_attr<40, 2, true>();
+  if (rc == DADD_OK) rc = flash_attr<40, 4, true>();
   if (rc == DADD_OK) rc = flash_attr<80, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<160, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<512, 1, false>();
@@ -521,7 +550,9 @@ extern "C" int dadd_self_attn_f16(const void* q, const void* k, const void* v, v
   a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d) {
-    case 40: return launch_flash<40, 2, true>(a, s);
+    case 40:   // 64 queries per wave once the grid still fills the chip (>= 2 blocks per CU)
+      return ((long)B * heads * ((N + 255) / 256) >= 512 && !getenv("DADD_FLASH_QF2"))
+                 ? launch_flash<40, 4, true>(a, s) : launch_flash<40, 2, true>(a, s);
     case 80: return launch_flash<80, 2, true>(a, s);
     case 160: return launch_flash<160, 2, true>(a, s);
     case 512: return launch_flash<512, 1, false>(a, s);

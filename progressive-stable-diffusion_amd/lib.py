@@ -74,8 +74,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *srcs, "-o",
-           LIB_PATH]
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  With the default AGPR form the
+    # attention softmax paid 144 v_accvgpr_read/write per 64-key tile (more than half of its VALU).
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+           "-amdgpu-mfma-vgpr-form=1", *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
