@@ -122,39 +122,47 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   int cur_kx = (p.taps == 9) ? cur_tap - 3 * cur_ky : 0;
   int fill_off = wave * 1024;                 // LDS byte offset of this wave's share of the slot to fill
 
-  auto issue = [&]() {   // LPT DMA loads for K tile cur_kt into the slot at fill_off, then advance
+  // One K tile of DMA work, split so that the pieces can be interleaved with MFMAs:
+  //   IssueCtx c = issue_begin();  issue_a(c, i) x NA;  issue_w(c, j) x NBJ;  issue_advance();
+  struct IssueCtx {
+    __amdgpu_buffer_rsrc_t rsA, rsW;
+    unsigned soff, koff;
+    char* sa;
+    int cs, cb, ky, kx, tap;
+    bool second;
+  };
+  auto issue_begin = [&]() {
+    IssueCtx c;
     const bool live = cur_kt < kt1;           // past the end: zero-record descriptors, no memory traffic
-    const bool second = cur_c >= p.C1;
-    const int cs = second ? p.C2 : p.C1;
-    const int cb = second ? cur_c - p.C1 : cur_c;
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? base2 : base1), 0,
-                                                       live ? (second ? rec2 : rec1) : 0, 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
-    char* sa = smem + fill_off;
+    c.second = cur_c >= p.C1;
+    c.cs = c.second ? p.C2 : p.C1;
+    c.cb = c.second ? cur_c - p.C1 : cur_c;
+    c.ky = cur_ky; c.kx = cur_kx; c.tap = cur_tap;
+    c.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(c.second ? base2 : base1), 0,
+                                              live ? (c.second ? rec2 : rec1) : 0, 0x00020000);
+    c.rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
+    c.sa = smem + fill_off;
+    c.soff = UPS ? (unsigned)(c.cb * 2) : (unsigned)(((cur_ky * p.Wi + cur_kx) * c.cs + c.cb) * 2);
+    c.koff = (unsigned)(cur_kt * (BK * 2));
+    return c;
+  };
+  auto issue_a = [&](const IssueCtx& c, int i) {
     if constexpr (!UPS) {
-      const unsigned soff = (unsigned)(((cur_ky * p.Wi + cur_kx) * cs + cb) * 2);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const bool ok = (a_mask[i] >> cur_tap) & 1u;
-        const unsigned vo = second ? a_v2[i] : a_v1[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sa + i * 4096), 16, ok ? vo : OOB, soff, 0, 0);
-      }
+      const bool ok = (a_mask[i] >> c.tap) & 1u;
+      const unsigned vo = c.second ? a_v2[i] : a_v1[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, ok ? vo : OOB, c.soff, 0, 0);
     } else {   // nearest-2x upsample: the source pixel is (iy>>1, ix>>1) of the virtual image
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int iy = a_y[i] + cur_ky, ix = a_x[i] + cur_kx;
-        const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
-        const unsigned vo = (unsigned)(((a_pix[i] + (iy >> 1) * p.Wi + (ix >> 1)) * cs + a_cc[i]) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(sa + i * 4096), 16, ok ? vo : OOB,
-                                                 (unsigned)(cb * 2), 0, 0);
-      }
+      const int iy = a_y[i] + c.ky, ix = a_x[i] + c.kx;
+      const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
+      const unsigned vo = (unsigned)(((a_pix[i] + (iy >> 1) * p.Wi + (ix >> 1)) * c.cs + a_cc[i]) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, ok ? vo : OOB, c.soff, 0, 0);
     }
-    const unsigned koff = (unsigned)(cur_kt * (BK * 2));
-#pragma unroll
-    for (int j = 0; j < NBJ; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(sa + A_BYTES + j * 4096), 16, w_v[j], koff, 0, 0);
-    // advance the cursor with selects only: a branch here would split the loop body into two
-    // scheduling regions and the DMA issue could not be interleaved with the MFMAs
+  };
+  auto issue_w = [&](const IssueCtx& c, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 0);
+  };
+  auto issue_advance = [&]() {
+    // selects only: a branch here would split the loop body into two scheduling regions
     ++cur_kt;
     const int c1 = cur_c + BK;
     const int wrap = c1 >= Cin ? 1 : 0;
@@ -166,6 +174,14 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
     cur_ky += w3;
     const int f1 = fill_off + STAGE;
     fill_off = f1 >= 4 * STAGE ? f1 - 4 * STAGE : f1;
+  };
+  auto issue = [&]() {   // whole tile at once (prologue)
+    const IssueCtx c = issue_begin();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) issue_a(c, i);
+#pragma unroll
+    for (int jj = 0; jj < NBJ; ++jj) issue_w(c, jj);
+    issue_advance();
   };
 
   f4 acc[J][4];
@@ -222,27 +238,39 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     const int n1 = comp_off + STAGE;
     const int next_off = n1 >= 4 * STAGE ? 0 : n1;
-    issue();                                  // tile it+3 -> slot of tile it-1
-    read_frags(comp_off, 1, xa1, wb1);
-    mma(xa0, wb0);
-    read_frags(next_off, 0, xa0, wb0);        // tile it+1 (harmless garbage after the last tile)
-    mma(xa1, wb1);
-    // interleave: first half of the MFMAs carries the DMA issue and the second-half fragment reads,
-    // the second half carries the prefetch of the next tile's fragments
+    // Hand-interleaved body: every MFMA is followed by ONE piece of the other work, so the in-order
+    // wave fills the matrix pipe's 16-cycle issue gaps instead of alternating MFMA-only runs (12 idle
+    // issue cycles each) with DMA/scalar-only runs (matrix pipe idle) — PMC before: MFMA busy 38 %.
+    //   first half  (operands xa0/wb0, prefetched): DMA issue of tile it+3, then the second-half reads
+    //   second half (operands xa1/wb1): prefetch of tile it+1's first-half fragments, cursor advance
+    const IssueCtx ic = issue_begin();
+    const char* ca = smem + comp_off + fa[1];
+    const char* cb1 = smem + comp_off + fb[1];
+    const char* na = smem + next_off + fa[0];
+    const char* nb = smem + next_off + fb[0];
 #pragma unroll
-    for (int g = 0; g < 4 * J; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-      if (g < 4 + J) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 DS read
-      if (g < LPT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // 1 VMEM read (DMA)
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                       // 2 VALU
-      __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);                       // 3 SALU
+    for (int k = 0; k < 4 * J; ++k) {
+      const int jj = k / 4, ii = k % 4;
+      acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
+      if (k < NA) issue_a(ic, k);
+      else if (k < LPT) issue_w(ic, k - NA);
+      else {
+        const int r = k - LPT;            // fragment read order = consumption order of the second half
+        if (r == 0) wb1[0] = *reinterpret_cast<const h8*>(cb1);
+        else if (r <= 4) xa1[r - 1] = *reinterpret_cast<const h8*>(ca + (r - 1) * 2048);
+        else if (r < 4 + J) wb1[r - 4] = *reinterpret_cast<const h8*>(cb1 + (r - 4) * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int g = 0; g < 4 * J; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (g < 4 + J) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+    for (int k = 0; k < 4 * J; ++k) {
+      const int jj = k / 4, ii = k % 4;
+      acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
+      if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(nb);
+      else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
+      else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(nb + (k - 4) * 2048);
+      else if (k == 4 + J) issue_advance();
+      __builtin_amdgcn_sched_barrier(0);
     }
     comp_off = next_off;
     __builtin_amdgcn_sched_barrier(0);
