@@ -13,7 +13,8 @@ struct GnArgs {
   const float* gamma;
   const float* beta;
   half_t* out;
-  float* ws;  // [B][nchunk][groups][2]
+  float* ws;     // [B][nchunk][groups][2] chunk partials
+  float* stats;  // [B][groups][2] mean, rstd (tail of the workspace)
   int C1, C2, C, HW, groups, cg, nchunk, rows_per_chunk, rows_per_block, TV, RP, silu;
   float eps;
 };
@@ -79,17 +80,48 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
   }
 }
 
-// pass 2: finish the statistics (8 threads per group, fixed order, double), fold gamma/beta into
-// per-channel scale/shift, apply to this block's rows.  grid (row blocks, B)
+// pass 2 (tiny): combine the chunk partials of one batch sample in a fixed order (double), write
+// mean / rstd per group.  grid (B), 256 threads = 32 groups x 8 lanes.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int g = t >> 3, sub = t & 7;
+  double a = 0.0, q = 0.0;
+  if (g < p.groups) {
+    for (int k = sub; k < p.nchunk; k += 8) {
+      const float* w = p.ws + (((size_t)b * p.nchunk + k) * p.groups + g) * 2;
+      a += (double)w[0];
+      q += (double)w[1];
+    }
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (g < p.groups && sub == 0) {
+    const double n = (double)p.HW * (double)p.cg;
+    const double mu = a / n;
+    double var = q / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    float* o2 = p.stats + ((size_t)b * p.groups + g) * 2;
+    o2[0] = (float)mu;
+    o2[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+}
+
+// pass 3: fold gamma/beta into per-channel scale/shift (C values per block), apply to this block's
+// rows.  grid (row blocks, B).  FIN = the block combines the chunk partials itself (few chunks: saves
+// the finalize launch, which costs more than it buys on the small feature maps).
+template <bool FIN>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
-  extern __shared__ float sm[];  // [C] scale, [C] shift, [groups] mean, [groups] rstd
+  extern __shared__ float sm[];  // [C] scale, [C] shift, [2*groups] mean/rstd (FIN)
   float* scale = sm;
   float* shift = sm + p.C;
-  float* mean = sm + 2 * p.C;
-  float* rstd = mean + p.groups;
   const int t = threadIdx.x, tv = t % p.TV, tr = t / p.TV;
   const int b = blockIdx.y;
-  {
+  const float* st = p.stats + (size_t)b * p.groups * 2;
+  if (FIN) {
+    float* lst = sm + 2 * p.C;
     const int g = t >> 3, sub = t & 7;
     double a = 0.0, q = 0.0;
     if (g < p.groups) {
@@ -109,16 +141,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
       const double mu = a / n;
       double var = q / n - mu * mu;
       if (var < 0.0) var = 0.0;
-      mean[g] = (float)mu;
-      rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+      lst[2 * g] = (float)mu;
+      lst[2 * g + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
     }
+    __syncthreads();
+    st = lst;
   }
-  __syncthreads();
   for (int c = t; c < p.C; c += 256) {
     const int g = c / p.cg;
-    const float sc = rstd[g] * p.gamma[c];
+    const float sc = st[2 * g + 1] * p.gamma[c];
     scale[c] = sc;
-    shift[c] = p.beta[c] - mean[g] * sc;
+    shift[c] = p.beta[c] - st[2 * g] * sc;
   }
   __syncthreads();
   if (tr >= p.RP) return;
@@ -288,13 +321,16 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const int nvec = C / 8;
   p.TV = nvec < 256 ? nvec : 256;
   p.RP = 256 / p.TV;
-  // enough blocks to cover the 256 CUs several times over, at least 2 passes of rows per block
+  // stat chunks: at least two passes of rows per block, at most 128 per sample
   int nchunk = HW / (2 * p.RP > 16 ? 2 * p.RP : 16);
+  if (nchunk > 128) nchunk = 128;
   if (nchunk < 1) nchunk = 1;
-  if (nchunk > DADD_GN_MAX_CHUNKS) nchunk = DADD_GN_MAX_CHUNKS;
+  if (nchunk > DADD_GN_MAX_CHUNKS - 1) nchunk = DADD_GN_MAX_CHUNKS - 1;
+  p.stats = ws + (size_t)B * (DADD_GN_MAX_CHUNKS - 1) * groups * 2;   // last chunk slot of the workspace
   p.rows_per_chunk = (HW + nchunk - 1) / nchunk;
   p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
-  p.rows_per_block = 4 * p.RP;
+  const bool fin_in_apply = nchunk <= 64;   // measured: the extra launch only pays on big maps
+  p.rows_per_block = (fin_in_apply ? 4 : 8) * p.RP;
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t slab_bytes = (size_t)HW * p.cg * sizeof(half_t);
@@ -307,7 +343,13 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, B), dim3(256), sm1, s, p);
   DADD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nrb, B), dim3(256), sm2, s, p);
+  if (fin_in_apply) {
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nrb, B), dim3(256), sm2, s, p);
+  } else {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
+    DADD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nrb, B), dim3(256), sm2, s, p);
+  }
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
