@@ -93,6 +93,59 @@ def test_golden_cross_attention_through_hip(hip, site, c, n, golden_dir):
         assert (run(kv2, cond3[:, :32], 1, 0.0) - ref).abs().max().item() < 4e-3, (site, mode)
 
 
+class _Attention(torch.nn.Module):
+    """What a diffusers Attention exposes to its processor (the attributes the reference reads)."""
+    spatial_norm = group_norm = norm_cross = None
+    residual_connection = False
+    rescale_output_factor = 1.0
+
+    def __init__(self, sd, ap, c, heads=8):
+        super().__init__()
+        self.heads = heads
+        self.to_q, self.to_k, self.to_v = (torch.nn.Linear(i, c, bias=False) for i in (c, 768, 768))
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(c, c), torch.nn.Dropout(0.0)])
+        self.load_state_dict({k[len(ap) + 1:]: v for k, v in sd.items()
+                              if k.startswith(ap + ".") and ".processor." not in k})
+
+
+@pytest.mark.parametrize("site,c,n", GI.XATTN_CASES)
+def test_golden_vectors_through_processor_classes(site, c, n, golden_dir):
+    """The drop-in processor classes (diffusers protocol, reference state-dict keys) called the way
+    diffusers calls them, against the reference's own outputs; also the reference's error behaviour."""
+    from progressive_stable_diffusion_amd import attention_processors as AP
+    from progressive_stable_diffusion_amd import weights as W
+    g = np.load(os.path.join(golden_dir, "xattn.npz"))
+    ush = W.unet_shapes()
+    ap = f"unet.unet.{site}.transformer_blocks.0.attn2"
+    sd = W.init_state_dict(ush, GI.SEED, gates=GI.GATES, warm_start_dis=False,
+                           keys=[k for k in ush if k.startswith(ap + ".")])
+    attn = _Attention(sd, ap, c).to(DEV)
+    x, cond3 = GI.xattn_inputs(c, n)
+    x, cond3 = x.to(DEV), cond3.to(DEV)
+    tag = site.replace(".", "_")
+    proc = AP.SplitInjectionAttentionProcessor(c, 768, block_type=AP.get_block_type(site + ".x"))
+    proc.load_state_dict({k[len(ap) + 11:]: v for k, v in sd.items() if k.startswith(ap + ".processor.")})
+    proc = proc.to(DEV)
+    assert set(proc.state_dict()) == {"anat_gate", "dis_gate", "to_k_dis.weight", "to_v_dis.weight"}
+    for lam in GI.LAMBDAS:
+        proc.delta_scale = lam
+        out = proc(attn, x, encoder_hidden_states=cond3)
+        torch.cuda.synchronize()
+        ref = torch.from_numpy(g[f"{tag}__split_l{lam}"])
+        assert out.shape == x.shape and out.dtype == x.dtype
+        assert (out.float().cpu() - ref).abs().max().item() < 4e-3, (site, lam)
+    for mode in GI.MODES:
+        base = AP.OrdinalIPAttnProcessor2_0(c, 768, frequency_mode=mode)
+        out = base(attn, x, encoder_hidden_states=cond3[:, :32].contiguous())
+        torch.cuda.synchronize()
+        assert (out.float().cpu() - torch.from_numpy(g[f"{tag}__base_{mode}"])).abs().max().item() < 4e-3
+    with pytest.raises(ValueError):
+        proc(attn, x, encoder_hidden_states=cond3[:, :32].contiguous())
+    attn.norm_cross = True
+    with pytest.raises(NotImplementedError):
+        AP.OrdinalIPAttnProcessor2_0(c, 768)(attn, x, encoder_hidden_states=cond3[:, :32].contiguous())
+
+
 @pytest.mark.parametrize("side,lam", [(16, 3.0), (24, 0.0)])
 def test_unet_call_matches_oracle(hip, full_sd, side, lam):
     """One module(latents, t, cond) call; side 24 gives ragged attention lengths (576/144/36/9 keys)."""
