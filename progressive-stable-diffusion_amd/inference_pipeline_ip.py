@@ -201,6 +201,32 @@ def _ddim_sample_ip(module: DiffusionModuleWithIP, target_labels: Tensor, source
     return out
 
 
+def _ddim_sample_batched(module: DiffusionModuleWithIP, target_labels: Tensor, source_labels: Tensor,
+                         structure_images: Tensor, sampling_steps: int, device: torch.device,
+                         eta: float = 0.0, image_scale: float = 1.0, steer_scale: float = 0.0,
+                         guidance_scale: float = 1.0, *, latents: Optional[Tensor] = None,
+                         use_graph: bool = True) -> Tensor:
+    """The sampler body as the reference's data-augmentation / evaluation pipelines copy it
+    (src/pipelines/inference/inference_pipeline_ip_data_augment.py:211-297,
+    src/pipelines/evaluation/evaluation_pipeline.py:472-565): an arbitrary batch of (source, target)
+    pairs, ONE structure image per sample (B,3,224,224) and independent initial noise per sample.
+    Same engine path as ``_ddim_sample_ip``."""
+    if structure_images.shape[0] != target_labels.shape[0]:
+        raise ValueError(f"structure_images batch {structure_images.shape[0]} != labels batch {target_labels.shape[0]}")
+    if latents is None:
+        side = module.cfg.dataset.image_size // 8
+        latents = torch.randn(target_labels.shape[0], module.cfg.model.latent_channels, side, side,
+                              device=device, dtype=torch.float32)
+    return _ddim_sample_ip(module, target_labels, source_labels, structure_images, sampling_steps, device,
+                           eta=eta, image_scale=image_scale, steer_scale=steer_scale,
+                           guidance_scale=guidance_scale, latents=latents, use_graph=use_graph)
+
+
+def _decode_latents(module: DiffusionModuleWithIP, latents: Tensor) -> Tensor:
+    """(inference_pipeline_ip_data_augment.py:300-310) decode -> [0,1] RGB fp32 on the CPU for saving."""
+    return _latents_to_images(module, latents).float().cpu()
+
+
 def _ddim_stochastic(module, latents, timesteps, cond, uncond, guidance_scale, eta):
     """eta > 0 (:457-468): per-step engine calls, update in torch (device RNG noise)."""
     ac = module.alphas_cumprod

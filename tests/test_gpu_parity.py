@@ -207,6 +207,31 @@ def test_config1_sampler_matches_oracle(full_sd, gates_on):
     assert di.max().item() < (3e-2 if gates_on else 0.1) and di.mean().item() < 4e-3
 
 
+def test_batched_sampler_matches_oracle(full_sd):
+    """``_ddim_sample_batched`` (the data-augmentation / evaluation copy of the sampler): one structure
+    image and one noise draw PER sample; 128x128, 4 steps, B=2, lambda=2."""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 128, 2)
+    target, source = torch.tensor([3.0, 0.0]), torch.tensor([1.0, 2.0])
+    pix = torch.rand(2, 3, 224, 224, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(99))
+    with torch.no_grad():
+        z = PIPE._ddim_sample_batched(mod, target.to(DEV), source.to(DEV), pix.to(DEV), 4, DEV,
+                                      steer_scale=2.0, latents=lat)
+        img = PIPE._decode_latents(mod, z)
+        feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
+        z_ref = OS.ddim_sample(full_sd, _ocfg(mod), target, source, feats, 4, lat, steer_scale=2.0)
+        img_ref = OS.latents_to_images(full_sd, _ocfg(mod), z_ref)
+    assert img.device.type == "cpu" and img.shape == (2, 3, 128, 128)
+    assert (z.cpu() - z_ref).abs().max().item() < 5e-2
+    d = (img - img_ref).abs()
+    assert d.max().item() < 3e-2 and d.mean().item() < 4e-3
+    with pytest.raises(ValueError):
+        PIPE._ddim_sample_batched(mod, target.to(DEV), source.to(DEV), pix[:1].to(DEV), 4, DEV)
+    z_rng = PIPE._ddim_sample_batched(mod, target.to(DEV), source.to(DEV), pix.to(DEV), 2, DEV)
+    assert z_rng.shape == (2, 4, 16, 16) and (z_rng[0] - z_rng[1]).abs().max().item() > 1e-3
+
+
 def test_full_size_properties(full_sd):
     """BASELINE config 2 size (512x512, 50 steps, B=4, lambda=3): properties that need no oracle run."""
     from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
