@@ -15,6 +15,7 @@
 // skip-connection concat are all folded into the A-tile address generation.
 #include "dadd_common.h"
 #include "igemm_args.h"
+#include <cstdlib>
 #include "igemm_epilogue.h"
 
 namespace {
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = tile_id % p.ntiles, mt = tile_id / p.ntiles;
+  int nt, mt;
+  tile_decode(p, tile_id, mt, nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int z = blockIdx.y;
   const int kt0 = z * p.kps;
@@ -313,6 +315,21 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   int tile_m = d->tile_m;
   DADD_REQUIRE(tile_m == 0 || tile_m == 64 || tile_m == 128, "igemm: tile_m must be 0, 64 or 128");
   if (tile_m == 0) tile_m = 128;
+  // tile order (igemm_args.h tile_decode): split the larger operand across the XCDs' L2s
+  a.mtiles = (a.M + tile_m - 1) / tile_m;
+  {
+    static const bool legacy = getenv("DADD_TILE_ORDER_LEGACY") != nullptr;   // A/B measurements only
+    const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * Cin, w_bytes = 2.0 * a.N * a.K;
+    if (legacy) {
+      a.gm = a.gn = 0;
+    } else if (a_bytes >= w_bytes) {
+      a.gm = (a.mtiles + 7) / 8;
+      a.gn = a.ntiles;
+    } else {
+      a.gm = a.mtiles;
+      a.gn = (a.ntiles + 7) / 8;
+    }
+  }
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)

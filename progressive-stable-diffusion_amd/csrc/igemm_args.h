@@ -17,6 +17,7 @@ struct IgemmArgs {
   int ldo, ldr, ld_rowvec;
   int splitk, flags;
   int M, K, nkt, kps, ntiles;
+  int mtiles, gm, gn;   // tile order: groups of gm x gn tiles (one of them spans its whole dimension); gm == 0: n fastest
 };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an XCD, each
@@ -28,6 +29,33 @@ struct IgemmArgs {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// Logical tile id -> (mt, nt).  An XCD owns a contiguous range of ids (xcd_remap), so the order of ids
+// decides what each 4 MiB L2 sees.  Measured with FETCH_SIZE (profiles/r01_q_traffic.txt): with n fastest
+// the ntiles column tiles of one row tile start together and each of them pulls the SAME activation
+// lines through the fabric (GEGLU N=2560: 198 MB fetched for 12 MB of operands), and a weight matrix
+// larger than the activation is re-read by all 8 XCDs.  So: the larger operand is the one split across
+// XCDs (gm < mtiles: row tiles split, A-heavy;  gn < ntiles: column tiles split, W-heavy) and inside a
+// group the row tile runs fastest, so concurrent workgroups read different activation rows and share
+// one or two weight tiles.  Bijective for any sizes.
+__device__ __forceinline__ void tile_decode(const IgemmArgs& p, int tile_id, int& mt, int& nt) {
+  if (p.gm == 0) {
+    nt = tile_id % p.ntiles;
+    mt = tile_id / p.ntiles;
+  } else if (p.gn >= p.ntiles) {          // groups of gm row tiles x all column tiles
+    const int per = p.gm * p.ntiles;
+    const int g = tile_id / per, idx = tile_id - g * per;
+    const int base = g * p.gm;
+    const int gsz = min(p.gm, p.mtiles - base);
+    mt = base + idx % gsz;
+    nt = idx / gsz;
+  } else {                                // groups of all row tiles x gn column tiles
+    const int per = p.mtiles * p.gn;
+    const int g = tile_id / per, idx = tile_id - g * per;
+    mt = idx % p.mtiles;
+    nt = g * p.gn + idx / p.mtiles;
+  }
 }
 
 int dadd_init_igemm_dma();

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = tile_id % p.ntiles, mt = tile_id / p.ntiles;
+  int nt, mt;
+  tile_decode(p, tile_id, mt, nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int z = blockIdx.y;
   const int kt0 = z * p.kps;
