@@ -149,13 +149,29 @@ def main():
             for _ in range(2):
                 loop._one_step(a.steer_scale, False, 1.0)
             fam = be.prof_end()
+            be.synchronize()
+            ovh = be.prof_event_overhead_ms()   # what the two event records cost with no kernel between them
         if st["launches"] > 0 and st["ms"] > 0:
+            raw_us = st["ms"] * 1e3 / st["launches"]
+            st["ms"] = max(st["ms"] - ovh * st["launches"], 1e-6)
+            fam["ms"] = max(fam["ms"] - ovh * fam["launches"], 1e-6)
             ach = st["flop"] / (st["ms"] * 1e-3) / 1e12
             fam_ach = fam["flop"] / (fam["ms"] * 1e-3) / 1e12
+            # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB), which a
+            # running program cannot collect on itself: the committed summary of scripts/pmc_traffic.sh is quoted
+            traffic = traffic_src = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+                    dom = json.load(f)["dominant"]
+                traffic, traffic_src = dom["traffic_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc)"
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": "igemm_dma_kernel<160,false> (LDS-DMA implicit-GEMM conv/linear)",
                     "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
-                    "traffic": None, "launches_per_step": st["launches"] // 2,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                    "launches_per_step": st["launches"] // 2,
                     "avg_launch_us": st["ms"] * 1e3 / st["launches"],
+                    "avg_launch_us_incl_event_overhead": raw_us, "event_pair_overhead_us": ovh * 1e3,
                     "flop_per_launch_avg": st["flop"] / st["launches"],
                     "share_of_step_flop": st["flop"] / (2 * 800.8e9 * a.batch) if a.image_size == 512 else None,
                     "all_igemm_launches": {"achieved": fam_ach, "launches_per_step": fam["launches"] // 2,

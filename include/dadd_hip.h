@@ -159,6 +159,8 @@ int dadd_graph_destroy(void* graph_exec);
  * out[0]=launches, out[1]=total ms, out[2]=total algorithmic flop (2*M*N*K). */
 int dadd_prof_begin(int kind);
 int dadd_prof_end(double out[3]);
+/* median interval (ms) of an empty event pair on `stream`: subtracted per launch by bench.py */
+int dadd_prof_event_overhead(void* stream, double* out_ms);
 
 #ifdef __cplusplus
 }

@@ -189,3 +189,9 @@ class HipBackend:
         out = (C.c_double * 3)()
         L.check(self.lib.dadd_prof_end(out))
         return {"launches": int(out[0]), "ms": out[1], "flop": out[2]}
+
+    def prof_event_overhead_ms(self):
+        """Median interval of an empty HIP-event pair on the backend stream."""
+        out = C.c_double(0.0)
+        L.check(self.lib.dadd_prof_event_overhead(self.s, C.byref(out)))
+        return out.value

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "dadd_common.h"
@@ -133,6 +134,28 @@ int dadd_prof_end(double out[3]) {
   out[0] = (double)n;
   out[1] = ms;
   out[2] = flop;
+  return DADD_OK;
+}
+
+// Median interval of an EMPTY (start, stop) event pair on `stream`: what the two hipEventRecord barrier
+// packets cost by themselves.  bench.py subtracts it from every bracketed launch so that the live
+// per-launch time is comparable with rocprofv3's kernel-only duration.
+int dadd_prof_event_overhead(void* stream, double* out_ms) {
+  DADD_REQUIRE(out_ms != nullptr, "prof_event_overhead: null out");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int N = 33;
+  hipEvent_t ev[2 * N];
+  for (auto& e : ev) DADD_HIP(hipEventCreate(&e));
+  for (int i = 0; i < N; ++i) {
+    DADD_HIP(hipEventRecord(ev[2 * i], s));
+    DADD_HIP(hipEventRecord(ev[2 * i + 1], s));
+  }
+  DADD_HIP(hipEventSynchronize(ev[2 * N - 1]));
+  float t[N];
+  for (int i = 0; i < N; ++i) DADD_HIP(hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]));
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  std::sort(t, t + N);
+  *out_ms = (double)t[N / 2];
   return DADD_OK;
 }
 

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "dadd_graph_destroy": (C.c_int, [vp]),
     "dadd_prof_begin": (C.c_int, [C.c_int]),
     "dadd_prof_end": (C.c_int, [C.POINTER(C.c_double)]),
+    "dadd_prof_event_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None
