@@ -334,9 +334,10 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
   const bool dma = tile_m == 128 && (d->flags & DADD_TUNE_NODMA) == 0;
-  // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false>, the
+  // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false, false>, the
   // dominant kernel of the UNet step (one row of a rocprofv3 --stats summary)
-  const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && dma && tile_n == 160 && !a.ups);
+  const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && dma && tile_n == 160 && !a.ups &&
+                                            !dadd_igemm_dma_persistent(a, nsplit));
   if (prof) dadd_prof_pre(s);
   if (dma)
     rc = dadd_launch_igemm_dma(a, tile_n, nsplit, s);

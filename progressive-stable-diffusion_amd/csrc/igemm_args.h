@@ -60,3 +60,4 @@ __device__ __forceinline__ void tile_decode(const IgemmArgs& p, int tile_id, int
 
 int dadd_init_igemm_dma();
 int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s);
+bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit);

@@ -17,6 +17,7 @@
 // against 36.8 KB per K tile); LDS-DMA removes that traffic from the VGPR->LDS path entirely.
 #include "dadd_common.h"
 #include "igemm_args.h"
+#include <cstdlib>
 #include "igemm_epilogue.h"
 
 namespace {
@@ -36,7 +37,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool UPS>
+template <int BN, bool UPS, bool PERS>
 __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type exists only in device code; the host
                                       // pass needs just the launch stub of this signature
@@ -51,13 +52,24 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
-  int nt, mt;
-  tile_decode(p, tile_id, mt, nt);
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int z = blockIdx.y;
-  const int kt0 = z * p.kps;
-  const int kt1 = min(p.nkt, kt0 + p.kps);
+  // Tiles of this workgroup.  One tile per workgroup, or (PERS, short-K GEMMs with more tiles than
+  // CUs) a contiguous range of logical tiles per workgroup: the DMA ring then runs as ONE stream of K
+  // tiles across output tiles, so the loads of tile t+1 are in flight under the MFMAs and the
+  // epilogue of tile t instead of every tile paying its own pipeline fill.
+  int tile_first, tile_count;
+  if constexpr (PERS) {
+    const int total = p.mtiles * p.ntiles, nwg = gridDim.x;
+    const int l = xcd_remap(blockIdx.x, nwg);
+    const int q = total / nwg, r = total - q * nwg;
+    tile_first = l * q + min(l, r);
+    tile_count = q + (l < r ? 1 : 0);
+  } else {
+    tile_first = xcd_remap(blockIdx.x, gridDim.x);
+    tile_count = 1;
+  }
+  const int z = PERS ? 0 : blockIdx.y;
+  const int kt0 = PERS ? 0 : z * p.kps;
+  const int kt1 = PERS ? p.nkt : min(p.nkt, kt0 + p.kps);
   const int nk = kt1 - kt0;
   const int Cin = p.C1 + p.C2;
   const int Hv = UPS ? 2 * p.Hi : p.Hi;
@@ -80,6 +92,11 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   // per-lane gather state: byte offsets of the window origin in both sources, validity bit per tap
   unsigned a_v1[NA], a_v2[NA], a_mask[NA];
   int a_pix[NA], a_y[NA], a_x[NA], a_cc[NA];   // only the upsample path uses these per tile
+  unsigned w_v[NBJ];
+  auto setup_tile = [&](int tile_id) {
+  int nt, mt;
+  tile_decode(p, tile_id, mt, nt);
+  const int m0 = mt * BM, n0 = nt * BN;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = (i * 4 + wave) * 8 + lrow;
@@ -106,13 +123,15 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
     }
     a_mask[i] = mask;
   }
-  unsigned w_v[NBJ];
 #pragma unroll
   for (int j = 0; j < NBJ; ++j) {
     const int row = (j * 4 + wave) * 8 + lrow;
     const int n = n0 + row;
     w_v[j] = (n < p.N) ? (unsigned)(((size_t)n * p.K + (lch ^ ((row >> 1) & 7)) * 8) * 2) : OOB;
   }
+  };
+  setup_tile(tile_first);
+  int iss_tile = tile_first, iss_left = tile_count;   // PERS: the tile the DMA cursor is in / tiles left
 
   // ---- wave-uniform tile cursor, advanced incrementally (no divisions in the loop): K tile -> tap,
   // (ky, kx), channel offset; plus the byte offsets of the ring slots being filled / computed.
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   };
   auto issue_begin = [&]() {
     IssueCtx c;
-    const bool live = cur_kt < kt1;           // past the end: zero-record descriptors, no memory traffic
+    const bool live = PERS ? iss_left > 0 : cur_kt < kt1;   // past the end: zero-record descriptors
     c.second = cur_c >= p.C1;
     c.cs = c.second ? p.C2 : p.C1;
     c.cb = c.second ? cur_c - p.C1 : cur_c;
@@ -175,6 +194,14 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
     cur_ky += w3;
     const int f1 = fill_off + STAGE;
     fill_off = f1 >= 4 * STAGE ? f1 - 4 * STAGE : f1;
+    if constexpr (PERS) {
+      if (cur_kt == kt1) {   // wave-uniform: the cursor rolls over into the next output tile
+        cur_kt = 0; cur_c = 0; cur_tap = 0; cur_ky = 0; cur_kx = 0;
+        ++iss_tile;
+        --iss_left;
+        if (iss_left > 0) setup_tile(iss_tile);
+      }
+    }
   };
   auto issue = [&]() {   // whole tile at once (prologue)
     const IssueCtx c = issue_begin();
@@ -186,10 +213,6 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   };
 
   f4 acc[J][4];
-#pragma unroll
-  for (int j = 0; j < J; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses inside a slot: per lane one byte offset per operand and K half (the XOR swizzle
   // term is the same for all 16-row fragments of a wave), fragment i / j adds an immediate i*2048.
@@ -231,8 +254,14 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   h8 xa0[4], wb0[J], xa1[4], wb1[J];
   read_frags(0, 0, xa0, wb0);
   int comp_off = 0;
+  bool started = false;
+  for (int tl = 0; tl < tile_count; ++tl) {
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < nk; ++it) {
-    if (it > 0) {
+    if (started) {
       wait_vmcnt<LPT>();   // tile it+1 landed (tile it+2's group may still be in flight)
       __builtin_amdgcn_s_barrier();
     }
@@ -274,49 +303,75 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     comp_off = next_off;
+    started = true;
     __builtin_amdgcn_sched_barrier(0);
   }
-  wait_vmcnt<0>();   // drain the dead tail loads before the epilogue's stores
+  if (tl == tile_count - 1) wait_vmcnt<0>();   // drain the dead tail loads before the last epilogue
 
-  // ---- epilogue (shared with igemm.hip)
-  igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
+  // ---- epilogue (shared with igemm.hip); with PERS the next tile's DMA loads stay in flight under it
+  int nt, mt;
+  tile_decode(p, tile_first + tl, mt, nt);
+  igemm_epilogue<J, 4, 64, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+  }
 #endif
 }
 
 template <int BN>
 constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2; }
 
-template <int BN, bool UPS>
+template <int BN, bool UPS, bool PERS>
 int set_attr() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN, UPS>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN, UPS, PERS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BN>()));
   return DADD_OK;
 }
 
+int g_num_cu = 0;
+
 }  // namespace
 
 int dadd_init_igemm_dma() {
-  int rc = set_attr<128, false>();
-  if (rc == DADD_OK) rc = set_attr<128, true>();
-  if (rc == DADD_OK) rc = set_attr<160, false>();
-  if (rc == DADD_OK) rc = set_attr<160, true>();
+  int rc = set_attr<128, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, true, false>();
+  if (rc == DADD_OK) rc = set_attr<160, false, false>();
+  if (rc == DADD_OK) rc = set_attr<160, true, false>();
+  if (rc == DADD_OK) rc = set_attr<128, false, true>();
+  if (rc == DADD_OK) rc = set_attr<160, false, true>();
+  int dev = 0;
+  DADD_HIP(hipGetDevice(&dev));
+  DADD_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   return rc;
+}
+
+// persistent ring over several output tiles: more tiles than CUs, no split-K, no upsample gather
+bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit) {
+  static const bool no_pers = getenv("DADD_NO_PERSIST") != nullptr;   // A/B measurements only
+  const int total = ((a.M + BM - 1) / BM) * a.ntiles;
+  return !no_pers && nsplit == 1 && !a.ups && g_num_cu > 0 && total > g_num_cu;
 }
 
 int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s) {
   const int mtiles = (a.M + BM - 1) / BM;
-  dim3 grid(mtiles * a.ntiles, nsplit);
+  const int total = mtiles * a.ntiles;
   // buffer offsets are 32-bit with bit 31 reserved as the out-of-range marker
   DADD_REQUIRE((size_t)a.B * a.Hi * a.Wi * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2 < 0x7FF00000ull &&
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "igemm(dma): operand larger than the 2 GiB buffer window");
   constexpr int smem160 = smem_bytes<160>(), smem128 = smem_bytes<128>();
+  if (dadd_igemm_dma_persistent(a, nsplit)) {
+    dim3 grid(g_num_cu);
+    if (tile_n == 160) hipLaunchKernelGGL((igemm_dma_kernel<160, false, true>), grid, dim3(256), smem160, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, true>), grid, dim3(256), smem128, s, a);
+    DADD_LAUNCH_CHECK();
+    return DADD_OK;
+  }
+  dim3 grid(total, nsplit);
   if (tile_n == 160) {
-    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true>), grid, dim3(256), smem160, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<160, false>), grid, dim3(256), smem160, s, a);
+    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true, false>), grid, dim3(256), smem160, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<160, false, false>), grid, dim3(256), smem160, s, a);
   } else {
-    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true>), grid, dim3(256), smem128, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<128, false>), grid, dim3(256), smem128, s, a);
+    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true, false>), grid, dim3(256), smem128, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, false>), grid, dim3(256), smem128, s, a);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

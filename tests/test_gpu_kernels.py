@@ -137,6 +137,48 @@ def test_igemm_kernel_variants(hip, tile_m, tune, splitk, shape):
     close(o, o_ref, 3e-3, 2e-3, f"{shape} tm{tile_m} tune{tune} sk{splitk}")
 
 
+@pytest.mark.parametrize("case", ["qkv", "k1", "k2_ragged", "conv", "geglu", "uneven"])
+def test_igemm_persistent_ring(hip, case):
+    """More 128-row output tiles than CUs and no split-K: the LDS-DMA kernel runs its ring as one stream
+    over a contiguous range of output tiles per workgroup (igemm_dma_kernel<.., PERS=true>).  Cases: K of
+    5 / 1 / 2 tiles (the DMA cursor is up to three OUTPUT tiles ahead of the MFMAs), ragged M and N,
+    a 3x3 gather, the GEGLU epilogue, and a tile count that does not divide by the workgroup count."""
+    from progressive_stable_diffusion_amd.engine import geglu_interleave
+    kw, flags, tile_n = {}, 1, 0
+    if case == "qkv":
+        b, h, c, n = 4, 64, 320, 960                    # 128 x 6 = 768 tiles
+    elif case == "k1":
+        b, h, c, n = 4, 48, 64, 640                     # 72 x 4 = 288 tiles, one K tile each
+    elif case == "k2_ragged":
+        b, h, c, n = 3, 61, 128, 800                    # M = 11163 (ragged), N = 800 = 5 x 160, 88 x 5 tiles
+    elif case == "conv":
+        b, h, c, n = 4, 64, 64, 640                     # 128 x 4 tiles, K = 576
+        kw = dict(taps=9, pad=1)
+    elif case == "geglu":
+        b, h, c, n = 4, 64, 320, 2560                   # 128 x 20 tiles of 128 x 128
+        flags, tile_n = 1 | 8, 128
+    else:
+        b, h, c, n = 1, 200, 192, 480                   # 313 x 3 = 939 tiles over 256 workgroups
+    k = c * kw.get("taps", 1)
+    x = rnd((b, h, h, c), 70)
+    if case == "geglu":
+        w32, b32 = rnd((n, k), 71, 1 / math.sqrt(k), F32), rnd((n,), 72, 0.1, F32)
+        w32, bias = geglu_interleave(w32, b32)
+        w = w32.to(F16)
+    else:
+        w, bias = rnd((n, k), 71, 1 / math.sqrt(k)), rnd((n,), 72, 0.1, F32)
+    n_out = n // 2 if case == "geglu" else n
+    res = None
+    if case in ("qkv", "conv", "uneven"):
+        res, flags = rnd((b, h, h, n), 73), flags | 4
+    o, o_ref = run_igemm(hip, x, w, (b, h, h, n_out), bias=bias, residual=res, flags=flags, tile_n=tile_n,
+                         tile_m=128, **kw)
+    close(o, o_ref, 3e-3, 3e-3, f"persistent {case}")
+    o2, _ = run_igemm(hip, x, w, (b, h, h, n_out), bias=bias, residual=res, flags=flags | 32, tile_n=tile_n,
+                      tile_m=128, **kw)        # register-staged kernel: same K order, same epilogue
+    assert torch.equal(o.cpu(), o2.cpu()), "persistent ring and register-staged kernel must agree bit for bit"
+
+
 def test_igemm_geglu(hip):
     from progressive_stable_diffusion_amd.engine import geglu_interleave
     m, c = 300, 320
