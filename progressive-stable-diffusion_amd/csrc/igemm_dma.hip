@@ -25,6 +25,14 @@ namespace {
 constexpr int BM = 128;
 constexpr int BK = 64;
 
+// Diagnostic builds only (scripts/exp_dma_limits.sh; the product library is built without the macro):
+// 1 = DMA stream without the MFMAs, 2 = MFMAs + fragment reads without the DMA stream.  They bound the
+// main loop from both sides (results are garbage by construction).
+#ifndef DADD_IGEMM_EXP
+#define DADD_IGEMM_EXP 0
+#endif
+constexpr int EXP = DADD_IGEMM_EXP;
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned OOB = 0x80000000u;   // beyond num_records of every descriptor: the load returns zeros
 
@@ -281,9 +289,10 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int k = 0; k < 4 * J; ++k) {
       const int jj = k / 4, ii = k % 4;
-      acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
-      if (k < NA) issue_a(ic, k);
-      else if (k < LPT) issue_w(ic, k - NA);
+      if constexpr (EXP != 1)
+        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
+      if (k < NA) { if constexpr (EXP != 2) issue_a(ic, k); }
+      else if (k < LPT) { if constexpr (EXP != 2) issue_w(ic, k - NA); }
       else {
         const int r = k - LPT;            // fragment read order = consumption order of the second half
         if (r == 0) wb1[0] = *reinterpret_cast<const h8*>(cb1);
@@ -295,7 +304,8 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int k = 0; k < 4 * J; ++k) {
       const int jj = k / 4, ii = k % 4;
-      acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
+      if constexpr (EXP != 1)
+        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
       if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(nb);
       else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
       else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(nb + (k - 4) * 2048);
