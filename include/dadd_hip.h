@@ -37,6 +37,7 @@ extern "C" {
 #define DADD_EPI_GEGLU 8    /* out[m][n/2] = hidden * gelu(gate); weight rows pre-interleaved */
 #define DADD_TUNE_SHALLOW 16 /* tuning: keep one K tile in flight instead of two (A/B measurements) */
 #define DADD_TUNE_NODMA 32   /* tuning: register-staged kernel instead of the LDS-DMA ring kernel */
+#define DADD_TUNE_PERSIST 64 /* tuning: LDS-DMA ring kept running over several output tiles per workgroup */
 
 /* cross-attention modes of dadd_tri_xattn_f16 */
 #define DADD_XATTN_SPLIT 0    /* triple pathway, independent softmaxes */
@@ -153,7 +154,7 @@ int dadd_graph_launch(void* graph_exec, void* stream);
 int dadd_graph_destroy(void* graph_exec);
 
 /* ---- in-library HIP-event timing of one kernel family (bench.py roofline) -------------------
- * kind 1 = every implicit GEMM, kind 2 = only igemm_dma_kernel<160,false,false> (the dominant kernel of
+ * kind 1 = every implicit GEMM, kind 2 = only igemm_dma_kernel<160,false,false,true> (the dominant kernel of
  * the UNet step).  While enabled (eager launches only, never during capture) every
  * launch of that family is bracketed by events on its own stream.  dadd_prof_end fills
  * out[0]=launches, out[1]=total ms, out[2]=total algorithmic flop (2*M*N*K). */

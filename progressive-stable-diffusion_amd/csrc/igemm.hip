@@ -264,7 +264,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags & 15;
+  a.flags = d->flags & (15 | DADD_TUNE_PERSIST);   // epilogue bits + the persistent-ring request
   const int Cin = a.C1 + a.C2;
   const bool geglu = (a.flags & DADD_EPI_GEGLU) != 0;
   a.ldo = d->ldo > 0 ? d->ldo : (geglu ? a.N / 2 : a.N);
@@ -334,7 +334,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
   const bool dma = tile_m == 128 && (d->flags & DADD_TUNE_NODMA) == 0;
-  // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false, false>, the
+  // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false, false, true>, the
   // dominant kernel of the UNet step (one row of a rocprofv3 --stats summary)
   const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && dma && tile_n == 160 && !a.ups &&
                                             !dadd_igemm_dma_persistent(a, nsplit));

@@ -45,8 +45,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool UPS, bool PERS>
-__global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
+template <int BN, bool UPS, bool PERS, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type exists only in device code; the host
                                       // pass needs just the launch stub of this signature
   constexpr int WN = BN / 2;
@@ -57,8 +57,15 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
+  // WS (wave specialisation): 8 waves, two per SIMD.  Waves 0-3 only read fragments and issue MFMAs,
+  // waves 4-7 only issue the DMA stream.  Measured with the diagnostic builds (profiles/r01_u_dma_limits.txt):
+  // in ONE instruction stream the two do not overlap — a DMA instruction holds its wave for ~60-180
+  // cycles at issue and with a single wave per SIMD the matrix pipe drains meanwhile (16384x640x5760:
+  // DMA alone 84 us, MFMA alone 91 us, together 154 us).
   const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = WS && wave_all >= 4;
+  const int wave = WS ? (wave_all & 3) : wave_all;   // compute role: (wm, wn); loader role: row share
   const int wm = wave >> 1, wn = wave & 1;
   // Tiles of this workgroup.  One tile per workgroup, or (PERS, short-K GEMMs with more tiles than
   // CUs) a contiguous range of logical tiles per workgroup: the DMA ring then runs as ONE stream of K
@@ -211,12 +218,14 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
       }
     }
   };
-  auto issue = [&]() {   // whole tile at once (prologue)
+  auto issue = [&]() {   // whole tile at once (prologue; loader waves)
     const IssueCtx c = issue_begin();
+    if constexpr (EXP != 2) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) issue_a(c, i);
+      for (int i = 0; i < NA; ++i) issue_a(c, i);
 #pragma unroll
-    for (int jj = 0; jj < NBJ; ++jj) issue_w(c, jj);
+      for (int jj = 0; jj < NBJ; ++jj) issue_w(c, jj);
+    }
     issue_advance();
   };
 
@@ -246,6 +255,84 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
       for (int i = 0; i < 4; ++i)
         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
   };
+
+  if constexpr (WS) {
+    static_assert(!PERS, "wave specialisation and the persistent ring are separate variants");
+    if (loader) {
+      // ---- loader waves: same ring protocol, DMA side only
+      issue();
+      issue();
+      issue();
+      wait_vmcnt<LPT>();
+      __builtin_amdgcn_s_barrier();
+      for (int it = 0; it < nk; ++it) {
+        if (it > 0) {
+          wait_vmcnt<LPT>();   // tile it+1 landed (this wave's share); tile it+2 may be in flight
+          __builtin_amdgcn_s_barrier();
+        }
+        issue();               // tile it+3 -> the slot of tile it-1, free since this barrier
+      }
+      wait_vmcnt<0>();
+      return;
+    }
+    // ---- compute waves
+    f4 acc[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+    const int fq = lane >> 4;
+    int fa[2], fb[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      fa[s2] = lds_off(wm * 64 + (lane & 15), s2 * 4 + fq) * 2;
+      fb[s2] = A_BYTES + lds_off(wn * WN + (lane & 15), s2 * 4 + fq) * 2;
+    }
+    __builtin_amdgcn_s_barrier();   // tiles 0 and 1 landed
+    __builtin_amdgcn_sched_barrier(0);
+    h8 xa0[4], wb0[J], xa1[4], wb1[J];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xa0[i] = *reinterpret_cast<const h8*>(smem + fa[0] + i * 2048);
+#pragma unroll
+    for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb[0] + j * 2048);
+    int comp_off = 0;
+    for (int it = 0; it < nk; ++it) {
+      if (it > 0) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int n1 = comp_off + STAGE;
+      const int next_off = n1 >= 4 * STAGE ? 0 : n1;
+      const char* ca = smem + comp_off + fa[1];
+      const char* cb1 = smem + comp_off + fb[1];
+      const char* na = smem + next_off + fa[0];
+      const char* nb = smem + next_off + fb[0];
+#pragma unroll
+      for (int k = 0; k < 4 * J; ++k) {     // first K half; the second half's fragments stream in behind
+        const int jj = k / 4, ii = k % 4;
+        if constexpr (EXP != 1)
+          acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
+        if (k == 0) wb1[0] = *reinterpret_cast<const h8*>(cb1);
+        else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(ca + (k - 1) * 2048);
+        else if (k < 4 + J) wb1[k - 4] = *reinterpret_cast<const h8*>(cb1 + (k - 4) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4 * J; ++k) {     // second K half; prefetch of tile it+1's first half
+        const int jj = k / 4, ii = k % 4;
+        if constexpr (EXP != 1)
+          acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
+        if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(nb);
+        else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
+        else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(nb + (k - 4) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      comp_off = next_off;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int nt, mt;
+    tile_decode(p, tile_first, mt, nt);
+    igemm_epilogue<J, 4, 64, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+    return;
+  }
 
   // ---- ring schedule.  Roles at iteration `it`: tile it computes, tile it+1 has LANDED (its first
   // fragments are prefetched while tile it's second half runs), tiles it+2, it+3 are in flight, and
@@ -329,9 +416,9 @@ __global__ __launch_bounds__(256, 1) void igemm_dma_kernel(const IgemmArgs p) {
 template <int BN>
 constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2; }
 
-template <int BN, bool UPS, bool PERS>
+template <int BN, bool UPS, bool PERS, bool WS>
 int set_attr() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN, UPS, PERS>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN, UPS, PERS, WS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BN>()));
   return DADD_OK;
 }
@@ -341,12 +428,16 @@ int g_num_cu = 0;
 }  // namespace
 
 int dadd_init_igemm_dma() {
-  int rc = set_attr<128, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, true, false>();
-  if (rc == DADD_OK) rc = set_attr<160, false, false>();
-  if (rc == DADD_OK) rc = set_attr<160, true, false>();
-  if (rc == DADD_OK) rc = set_attr<128, false, true>();
-  if (rc == DADD_OK) rc = set_attr<160, false, true>();
+  int rc = set_attr<128, false, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, true, false, false>();
+  if (rc == DADD_OK) rc = set_attr<160, false, false, false>();
+  if (rc == DADD_OK) rc = set_attr<160, true, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, false, true, false>();
+  if (rc == DADD_OK) rc = set_attr<160, false, true, false>();
+  if (rc == DADD_OK) rc = set_attr<128, false, false, true>();
+  if (rc == DADD_OK) rc = set_attr<128, true, false, true>();
+  if (rc == DADD_OK) rc = set_attr<160, false, false, true>();
+  if (rc == DADD_OK) rc = set_attr<160, true, false, true>();
   int dev = 0;
   DADD_HIP(hipGetDevice(&dev));
   DADD_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -357,7 +448,7 @@ int dadd_init_igemm_dma() {
 bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit) {
   static const bool no_pers = getenv("DADD_NO_PERSIST") != nullptr;   // A/B measurements only
   const int total = ((a.M + BM - 1) / BM) * a.ntiles;
-  return !no_pers && nsplit == 1 && !a.ups && g_num_cu > 0 && total > g_num_cu;
+  return !no_pers && (a.flags & DADD_TUNE_PERSIST) && nsplit == 1 && !a.ups && g_num_cu > 0 && total > g_num_cu;
 }
 
 int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s) {
@@ -370,18 +461,27 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_
   constexpr int smem160 = smem_bytes<160>(), smem128 = smem_bytes<128>();
   if (dadd_igemm_dma_persistent(a, nsplit)) {
     dim3 grid(g_num_cu);
-    if (tile_n == 160) hipLaunchKernelGGL((igemm_dma_kernel<160, false, true>), grid, dim3(256), smem160, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, true>), grid, dim3(256), smem128, s, a);
+    if (tile_n == 160) hipLaunchKernelGGL((igemm_dma_kernel<160, false, true, false>), grid, dim3(256), smem160, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, true, false>), grid, dim3(256), smem128, s, a);
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }
   dim3 grid(total, nsplit);
-  if (tile_n == 160) {
-    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true, false>), grid, dim3(256), smem160, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<160, false, false>), grid, dim3(256), smem160, s, a);
+  static const bool no_ws = getenv("DADD_NO_WS") != nullptr;   // A/B measurements only
+  if (!no_ws) {
+    if (tile_n == 160) {
+      if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true, false, true>), grid, dim3(512), smem160, s, a);
+      else hipLaunchKernelGGL((igemm_dma_kernel<160, false, false, true>), grid, dim3(512), smem160, s, a);
+    } else {
+      if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true, false, true>), grid, dim3(512), smem128, s, a);
+      else hipLaunchKernelGGL((igemm_dma_kernel<128, false, false, true>), grid, dim3(512), smem128, s, a);
+    }
+  } else if (tile_n == 160) {
+    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true, false, false>), grid, dim3(256), smem160, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<160, false, false, false>), grid, dim3(256), smem160, s, a);
   } else {
-    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true, false>), grid, dim3(256), smem128, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, false>), grid, dim3(256), smem128, s, a);
+    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true, false, false>), grid, dim3(256), smem128, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, false, false>), grid, dim3(256), smem128, s, a);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

@@ -16,7 +16,7 @@ SOURCES = ("igemm.hip", "igemm_dma.hip", "norm.hip", "attention.hip", "elementwi
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
-TUNE_SHALLOW, TUNE_NODMA = 16, 32
+TUNE_SHALLOW, TUNE_NODMA, TUNE_PERSIST = 16, 32, 64
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
 GN_MAX_CHUNKS = 256
 

@@ -139,8 +139,8 @@ def test_igemm_kernel_variants(hip, tile_m, tune, splitk, shape):
 
 @pytest.mark.parametrize("case", ["qkv", "k1", "k2_ragged", "conv", "geglu", "uneven"])
 def test_igemm_persistent_ring(hip, case):
-    """More 128-row output tiles than CUs and no split-K: the LDS-DMA kernel runs its ring as one stream
-    over a contiguous range of output tiles per workgroup (igemm_dma_kernel<.., PERS=true>).  Cases: K of
+    """More 128-row output tiles than CUs and no split-K: on request (DADD_TUNE_PERSIST) the LDS-DMA kernel
+    runs its ring as one stream over a contiguous range of output tiles per workgroup.  Cases: K of
     5 / 1 / 2 tiles (the DMA cursor is up to three OUTPUT tiles ahead of the MFMAs), ragged M and N,
     a 3x3 gather, the GEGLU epilogue, and a tile count that does not divide by the workgroup count."""
     from progressive_stable_diffusion_amd.engine import geglu_interleave
@@ -171,9 +171,12 @@ def test_igemm_persistent_ring(hip, case):
     res = None
     if case in ("qkv", "conv", "uneven"):
         res, flags = rnd((b, h, h, n), 73), flags | 4
-    o, o_ref = run_igemm(hip, x, w, (b, h, h, n_out), bias=bias, residual=res, flags=flags, tile_n=tile_n,
-                         tile_m=128, **kw)
+    o, o_ref = run_igemm(hip, x, w, (b, h, h, n_out), bias=bias, residual=res, flags=flags | 64, tile_n=tile_n,
+                         tile_m=128, **kw)       # 64 = DADD_TUNE_PERSIST
     close(o, o_ref, 3e-3, 3e-3, f"persistent {case}")
+    o3, _ = run_igemm(hip, x, w, (b, h, h, n_out), bias=bias, residual=res, flags=flags, tile_n=tile_n,
+                      tile_m=128, **kw)          # default: wave-specialised ring, one tile per workgroup
+    assert torch.equal(o.cpu(), o3.cpu()), "persistent and wave-specialised rings must agree bit for bit"
     o2, _ = run_igemm(hip, x, w, (b, h, h, n_out), bias=bias, residual=res, flags=flags | 32, tile_n=tile_n,
                       tile_m=128, **kw)        # register-staged kernel: same K order, same epilogue
     assert torch.equal(o.cpu(), o2.cpu()), "persistent ring and register-staged kernel must agree bit for bit"
