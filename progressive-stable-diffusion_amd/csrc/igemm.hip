@@ -330,6 +330,10 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
       a.gn = (a.ntiles + 7) / 8;
     }
   }
+  {
+    static const int korder_env = getenv("DADD_K_ORDER") ? atoi(getenv("DADD_K_ORDER")) : -1;   // A/B only
+    a.korder = (a.taps == 9 && (korder_env < 0 ? 1 : korder_env)) ? 1 : 0;
+  }
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)

@@ -17,6 +17,7 @@ struct IgemmArgs {
   int ldo, ldr, ld_rowvec;
   int splitk, flags;
   int M, K, nkt, kps, ntiles;
+  int korder;           // LDS-DMA kernel only: 0 = channels fastest, 1 = taps fastest (3x3)
   int mtiles, gm, gn;   // tile order: groups of gm x gn tiles (one of them spans its whole dimension); gm == 0: n fastest
 };
 

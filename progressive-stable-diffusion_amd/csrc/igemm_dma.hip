@@ -150,9 +150,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
 
   // ---- wave-uniform tile cursor, advanced incrementally (no divisions in the loop): K tile -> tap,
   // (ky, kx), channel offset; plus the byte offsets of the ring slots being filled / computed.
+  // K order.  korder 0: channels fastest (k = tap*Cin + c ascending, the order of igemm.hip).  korder 1
+  // (3x3 only): TAP fastest — the nine taps of one 64-channel chunk are consecutive K tiles, so their
+  // activation tiles are shifted copies of the same ~264 pixel lines (one 128-B line per pixel per
+  // chunk) and can hit in the CU's L1 instead of each going to L2; the weight stream is marked
+  // non-temporal so that it does not evict them.  Same products, different summation order.
+  const bool tapfast = p.korder != 0;
   int cur_kt = kt0;
-  int cur_tap = (kt0 * BK) / Cin;
-  int cur_c = kt0 * BK - cur_tap * Cin;
+  int cur_tap = tapfast ? kt0 % 9 : (kt0 * BK) / Cin;
+  int cur_c = tapfast ? (kt0 / 9) * BK : kt0 * BK - cur_tap * Cin;
   int cur_ky = (p.taps == 9) ? cur_tap / 3 : 0;
   int cur_kx = (p.taps == 9) ? cur_tap - 3 * cur_ky : 0;
   int fill_off = wave * 1024;                 // LDS byte offset of this wave's share of the slot to fill
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     c.rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
     c.sa = smem + fill_off;
     c.soff = UPS ? (unsigned)(c.cb * 2) : (unsigned)(((cur_ky * p.Wi + cur_kx) * c.cs + c.cb) * 2);
-    c.koff = (unsigned)(cur_kt * (BK * 2));
+    c.koff = (unsigned)((cur_tap * Cin + cur_c) * 2);
     return c;
   };
   auto issue_a = [&](const IssueCtx& c, int i) {
@@ -194,19 +200,33 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     }
   };
   auto issue_w = [&](const IssueCtx& c, int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 0);
+    if (tapfast)   // aux 2 = nt (streamed once per workgroup)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 2);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 0);
   };
   auto issue_advance = [&]() {
     // selects only: a branch here would split the loop body into two scheduling regions
     ++cur_kt;
-    const int c1 = cur_c + BK;
-    const int wrap = c1 >= Cin ? 1 : 0;
-    cur_c = wrap ? 0 : c1;
-    cur_tap += wrap;
-    const int kx1 = cur_kx + wrap;
-    const int w3 = kx1 == 3 ? 1 : 0;
-    cur_kx = w3 ? 0 : kx1;
-    cur_ky += w3;
+    if (tapfast) {             // wave-uniform and loop-invariant
+      const int kx1 = cur_kx + 1;
+      const int w3 = kx1 == 3 ? 1 : 0;
+      cur_kx = w3 ? 0 : kx1;
+      const int ky1 = cur_ky + w3;
+      const int w9 = ky1 == 3 ? 1 : 0;
+      cur_ky = w9 ? 0 : ky1;
+      cur_tap = w9 ? 0 : cur_tap + 1;
+      cur_c += w9 ? BK : 0;
+    } else {
+      const int c1 = cur_c + BK;
+      const int wrap = c1 >= Cin ? 1 : 0;
+      cur_c = wrap ? 0 : c1;
+      cur_tap += wrap;
+      const int kx1 = cur_kx + wrap;
+      const int w3 = kx1 == 3 ? 1 : 0;
+      cur_kx = w3 ? 0 : kx1;
+      cur_ky += w3;
+    }
     const int f1 = fill_off + STAGE;
     fill_off = f1 >= 4 * STAGE ? f1 - 4 * STAGE : f1;
     if constexpr (PERS) {
