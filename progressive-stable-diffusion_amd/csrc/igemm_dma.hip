@@ -153,12 +153,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
   // K order.  korder 0: channels fastest (k = tap*Cin + c ascending, the order of igemm.hip).  korder 1
   // (3x3 only): TAP fastest — the nine taps of one 64-channel chunk are consecutive K tiles, so their
   // activation tiles are shifted copies of the same ~264 pixel lines (one 128-B line per pixel per
-  // chunk) and can hit in the CU's L1 instead of each going to L2; the weight stream is marked
-  // non-temporal so that it does not evict them.  Same products, different summation order.
+  // chunk) and can hit in the CU's L1 instead of each going to L2.  Same products, different
+  // summation order.
   const bool tapfast = p.korder != 0;
   int cur_kt = kt0;
-  int cur_tap = tapfast ? kt0 % 9 : (kt0 * BK) / Cin;
-  int cur_c = tapfast ? (kt0 / 9) * BK : kt0 * BK - cur_tap * Cin;
+  // (the runtime division runs on the VALU: pin the wave-uniform results to SGPRs, or the scalar offset
+  // operand of every weight DMA is legalised with a waterfall loop)
+  int cur_tap = __builtin_amdgcn_readfirstlane(tapfast ? kt0 % 9 : (kt0 * BK) / Cin);
+  int cur_c = __builtin_amdgcn_readfirstlane(tapfast ? (kt0 / 9) * BK : kt0 * BK - cur_tap * Cin);
+  int cur_koff = __builtin_amdgcn_readfirstlane((cur_tap * Cin + cur_c) * 2);   // byte offset of the K tile in a weight row
   int cur_ky = (p.taps == 9) ? cur_tap / 3 : 0;
   int cur_kx = (p.taps == 9) ? cur_tap - 3 * cur_ky : 0;
   int fill_off = wave * 1024;                 // LDS byte offset of this wave's share of the slot to fill
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     c.rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
     c.sa = smem + fill_off;
     c.soff = UPS ? (unsigned)(c.cb * 2) : (unsigned)(((cur_ky * p.Wi + cur_kx) * c.cs + c.cb) * 2);
-    c.koff = (unsigned)((cur_tap * Cin + cur_c) * 2);
+    c.koff = (unsigned)cur_koff;
     return c;
   };
   auto issue_a = [&](const IssueCtx& c, int i) {
@@ -200,38 +203,29 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     }
   };
   auto issue_w = [&](const IssueCtx& c, int j) {
-    if (tapfast)   // aux 2 = nt (streamed once per workgroup)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 2);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 0);
   };
   auto issue_advance = [&]() {
     // selects only: a branch here would split the loop body into two scheduling regions
     ++cur_kt;
-    if (tapfast) {             // wave-uniform and loop-invariant
-      const int kx1 = cur_kx + 1;
-      const int w3 = kx1 == 3 ? 1 : 0;
-      cur_kx = w3 ? 0 : kx1;
-      const int ky1 = cur_ky + w3;
-      const int w9 = ky1 == 3 ? 1 : 0;
-      cur_ky = w9 ? 0 : ky1;
-      cur_tap = w9 ? 0 : cur_tap + 1;
-      cur_c += w9 ? BK : 0;
-    } else {
-      const int c1 = cur_c + BK;
-      const int wrap = c1 >= Cin ? 1 : 0;
-      cur_c = wrap ? 0 : c1;
-      cur_tap += wrap;
-      const int kx1 = cur_kx + wrap;
-      const int w3 = kx1 == 3 ? 1 : 0;
-      cur_kx = w3 ? 0 : kx1;
-      cur_ky += w3;
-    }
+    // selects only (a branch here makes the compiler treat the cursor — and with it the buffer
+    // descriptors — as divergent: every DMA instruction then sits in a waterfall loop, 2.7x slower)
+    const int c1 = cur_c + BK;
+    const int cwrap = c1 >= Cin ? 1 : 0;
+    const int kx1 = cur_kx + (tapfast ? 1 : cwrap);
+    const int w3 = kx1 == 3 ? 1 : 0;
+    cur_kx = w3 ? 0 : kx1;
+    const int ky1 = cur_ky + w3;
+    const int w9 = (tapfast && ky1 == 3) ? 1 : 0;
+    cur_ky = w9 ? 0 : ky1;
+    cur_koff += tapfast ? (w9 ? (BK - 8 * Cin) * 2 : Cin * 2) : BK * 2;   // own scalar chain: cur_tap lives in a VGPR
+    cur_tap = tapfast ? (w9 ? 0 : cur_tap + 1) : cur_tap + cwrap;
+    cur_c = tapfast ? cur_c + (w9 ? BK : 0) : (cwrap ? 0 : c1);
     const int f1 = fill_off + STAGE;
     fill_off = f1 >= 4 * STAGE ? f1 - 4 * STAGE : f1;
     if constexpr (PERS) {
       if (cur_kt == kt1) {   // wave-uniform: the cursor rolls over into the next output tile
-        cur_kt = 0; cur_c = 0; cur_tap = 0; cur_ky = 0; cur_kx = 0;
+        cur_kt = 0; cur_c = 0; cur_tap = 0; cur_ky = 0; cur_kx = 0; cur_koff = 0;
         ++iss_tile;
         --iss_left;
         if (iss_left > 0) setup_tile(iss_tile);
@@ -277,15 +271,16 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
   };
 
   if constexpr (WS) {
-    static_assert(!PERS, "wave specialisation and the persistent ring are separate variants");
+    const int total_kt = tile_count * nk;   // PERS: one stream of K tiles over this workgroup's output tiles
     if (loader) {
-      // ---- loader waves: same ring protocol, DMA side only
+      // ---- loader waves: same ring protocol, DMA side only (with PERS the cursor rolls from one output
+      // tile into the next inside issue(), including the per-tile address setup — off the MFMA waves)
       issue();
       issue();
       issue();
       wait_vmcnt<LPT>();
       __builtin_amdgcn_s_barrier();
-      for (int it = 0; it < nk; ++it) {
+      for (int it = 0; it < total_kt; ++it) {
         if (it > 0) {
           wait_vmcnt<LPT>();   // tile it+1 landed (this wave's share); tile it+2 may be in flight
           __builtin_amdgcn_s_barrier();
@@ -297,10 +292,6 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     }
     // ---- compute waves
     f4 acc[J][4];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
     const int fq = lane >> 4;
     int fa[2], fb[2];
 #pragma unroll
@@ -316,8 +307,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
 #pragma unroll
     for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb[0] + j * 2048);
     int comp_off = 0;
+    bool started = false;
+    for (int tl = 0; tl < tile_count; ++tl) {
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < nk; ++it) {
-      if (it > 0) __builtin_amdgcn_s_barrier();
+      if (started) __builtin_amdgcn_s_barrier();
+      started = true;
       __builtin_amdgcn_sched_barrier(0);
       const int n1 = comp_off + STAGE;
       const int next_off = n1 >= 4 * STAGE ? 0 : n1;
@@ -349,8 +347,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
       __builtin_amdgcn_sched_barrier(0);
     }
     int nt, mt;
-    tile_decode(p, tile_first, mt, nt);
+    tile_decode(p, tile_first + tl, mt, nt);
     igemm_epilogue<J, 4, 64, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+    }
     return;
   }
 
@@ -452,8 +451,8 @@ int dadd_init_igemm_dma() {
   if (rc == DADD_OK) rc = set_attr<128, true, false, false>();
   if (rc == DADD_OK) rc = set_attr<160, false, false, false>();
   if (rc == DADD_OK) rc = set_attr<160, true, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, false, true, false>();
-  if (rc == DADD_OK) rc = set_attr<160, false, true, false>();
+  if (rc == DADD_OK) rc = set_attr<128, false, true, true>();
+  if (rc == DADD_OK) rc = set_attr<160, false, true, true>();
   if (rc == DADD_OK) rc = set_attr<128, false, false, true>();
   if (rc == DADD_OK) rc = set_attr<128, true, false, true>();
   if (rc == DADD_OK) rc = set_attr<160, false, false, true>();
@@ -481,8 +480,8 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_
   constexpr int smem160 = smem_bytes<160>(), smem128 = smem_bytes<128>();
   if (dadd_igemm_dma_persistent(a, nsplit)) {
     dim3 grid(g_num_cu);
-    if (tile_n == 160) hipLaunchKernelGGL((igemm_dma_kernel<160, false, true, false>), grid, dim3(256), smem160, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, true, false>), grid, dim3(256), smem128, s, a);
+    if (tile_n == 160) hipLaunchKernelGGL((igemm_dma_kernel<160, false, true, true>), grid, dim3(512), smem160, s, a);
+    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, true, true>), grid, dim3(512), smem128, s, a);
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }

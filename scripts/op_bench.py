@@ -112,11 +112,15 @@ def main():
                 tiles = -(-m // tm) * -(-n // (k.get("tile_n") or 160))
                 if sk > 1 and tiles * sk > 2048:
                     continue
-                for shallow in ((0, 2) if tm == 128 else (0, 1)):     # 2 = LDS-DMA ring kernel
-                    tune = {0: L.TUNE_NODMA, 1: L.TUNE_NODMA | L.TUNE_SHALLOW, 2: 0}[shallow]
+                for shallow in ((0, 2, 3) if tm == 128 else (0, 1)):  # 2 = LDS-DMA ring kernel, 3 = persistent ring
+                    if shallow == 3 and (sk > 1 or ups or tiles <= 256):
+                        continue
+                    tune = {0: L.TUNE_NODMA, 1: L.TUNE_NODMA | L.TUNE_SHALLOW, 2: 0, 3: L.TUNE_PERSIST}[shallow]
                     kw = dict(k)
                     kw.update(tile_m=tm, splitk=sk, partial=partial if sk > 1 else None,
                               flags=(k.get("flags", 0) & 15) | tune)
+                    if geglu:
+                        kw["tile_n"] = 128
                     try:
                         t = timeit(be, lambda: fn(*a, **kw), iters=10, warm=2)
                     except Exception as ex:      # noqa: BLE001
@@ -124,7 +128,7 @@ def main():
                         continue
                     variants.append((t, tm, sk, shallow))
                     if t < best[0]:
-                        best = (t, f"tm{tm} sk{sk} {('reg2', 'reg1', 'dma')[shallow]}")
+                        best = (t, f"tm{tm} sk{sk} {('reg2', 'reg1', 'dma', 'dmaP')[shallow]}")
         variants.sort()
         rows.append({"op": "igemm", "M": m, "N": n, "K": kk, "taps": taps, "stride": stride, "ups": ups,
                      "cat": cat, "flags": flags, "count": cnt, "us_current": t_cur,
