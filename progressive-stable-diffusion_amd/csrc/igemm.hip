@@ -332,12 +332,17 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   }
   {
     static const int korder_env = getenv("DADD_K_ORDER") ? atoi(getenv("DADD_K_ORDER")) : -1;   // A/B only
-    a.korder = (a.taps == 9 && (korder_env < 0 ? 1 : korder_env)) ? 1 : 0;
+    // taps-fastest order measured no different from channels-fastest (the DMA stream is bound by its
+    // instruction issue rate, not by L2->L1 bytes: profiles/r01_x_dma_limits.txt) -> opt-in only
+    a.korder = (a.taps == 9 && korder_env > 0) ? 1 : 0;
   }
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
   const bool dma = tile_m == 128 && (d->flags & DADD_TUNE_NODMA) == 0;
+  // persistent ring: a workgroup walks a contiguous run of tiles; with the column tile fastest the run
+  // keeps ONE activation row tile (L2-hot after the first tile) and streams the weight tiles
+  if (dma && dadd_igemm_dma_persistent(a, nsplit)) a.gm = a.gn = 0;
   // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false, false, true>, the
   // dominant kernel of the UNet step (one row of a rocprofv3 --stats summary)
   const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && dma && tile_n == 160 && !a.ups &&
