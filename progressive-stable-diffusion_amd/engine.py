@@ -74,18 +74,27 @@ def geglu_interleave(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, to
 def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> Tuple[int, int, int]:
     """(tile_m, splitk, tune_flags) for one implicit GEMM, from measurements over every layer shape
     of the B=4 / 512x512 step on MI355X (scripts/op_bench.py, profiles/r01_*_op_bench.txt):
-      * K >= 16 tiles: the LDS-DMA ring kernel, 128-row tiles, ONE block per CU (it hides latency with
-        its ring, not with occupancy) -> split K until the grid reaches ~256 blocks;
-      * short K (<= 960) and the GEGLU projection: the register-staged kernel, two blocks per CU,
-        64-row tiles when 128-row tiles would not give ~512 blocks."""
+      * K >= 12 tiles: the wave-specialised LDS-DMA ring kernel, 128-row tiles, ONE workgroup per CU;
+        split K only while a slice keeps >= 16 K tiles (8 on the tiny 8x8 / 16x16 grids) and the grid
+        stays near 256 workgroups — the fp32 slabs and the finish kernel cost more than idle CUs below that;
+      * short K with more 128-row tiles than CUs (qkv, the GEGLU projection at 32x32): the same kernel
+        with its ring kept running over a run of output tiles per workgroup (DADD_TUNE_PERSIST);
+      * other short-K linears: the register-staged kernel, two workgroups per CU, 64-row tiles when
+        128-row tiles would not give ~512 workgroups;
+      * GEGLU at 64x64 (2560 tiles, erf epilogue as long as the MFMAs): register-staged 64-row tiles."""
     nkt = k // 64
     nt = math.ceil(n / tile_n)
     t128 = math.ceil(m / 128) * nt
     if geglu:
-        return 64, 1, L.TUNE_NODMA | L.TUNE_SHALLOW
-    if nkt >= 16:
-        sk = max(1, min(round(N_CU / t128), nkt // 5, 32))
+        if m >= 16384:
+            return 64, 1, L.TUNE_NODMA | L.TUNE_SHALLOW
+        return 128, 1, (L.TUNE_PERSIST if t128 >= 4 * N_CU else 0)
+    if nkt >= 12:
+        per = 16 if t128 > 16 else 8
+        sk = max(1, min(round(N_CU / t128), nkt // per, 32))
         return 128, sk, 0
+    if t128 > N_CU:
+        return 128, 1, L.TUNE_PERSIST
     return (128 if t128 >= 2 * N_CU else 64), 1, L.TUNE_NODMA
 
 

@@ -53,13 +53,17 @@ def test_splitk_heuristic():
     # policy measured with scripts/op_bench.py on MI355X (profiles/r01_*_op_bench.txt)
     from progressive_stable_diffusion_amd import lib as L
     assert E.choose_tiling(16384, 2560, 320, 128, geglu=True) == (64, 1, L.TUNE_NODMA | L.TUNE_SHALLOW)
+    assert E.choose_tiling(4096, 5120, 640, 128, geglu=True) == (128, 1, L.TUNE_PERSIST)   # 1280 tiles, 5 per CU
+    assert E.choose_tiling(1024, 10240, 1280, 128, geglu=True) == (128, 1, 0)
     assert E.choose_tiling(16384, 320, 320, 160) == (64, 1, L.TUNE_NODMA)   # short-K linear: register kernel
-    assert E.choose_tiling(16384, 960, 320, 160) == (128, 1, L.TUNE_NODMA)
+    assert E.choose_tiling(16384, 960, 320, 160) == (128, 1, L.TUNE_PERSIST)  # qkv: 768 tiles, ring over 3 tiles
+    assert E.choose_tiling(4096, 1920, 640, 160) == (128, 1, L.TUNE_PERSIST)
     assert E.choose_tiling(16384, 320, 5760, 160) == (128, 1, 0)           # 256 tiles: one per CU, DMA ring
     assert E.choose_tiling(4096, 640, 5760, 160) == (128, 2, 0)
+    assert E.choose_tiling(4096, 640, 1280, 160) == (128, 1, 0)            # 20 K tiles: splitting costs more
     assert E.choose_tiling(1024, 1280, 11520, 160) == (128, 4, 0)
     assert E.choose_tiling(256, 1280, 11520, 160) == (128, 16, 0)           # 8x8 level: 16 tiles x 16 splits
-    assert E.choose_tiling(1024, 1280, 1280, 160) == (128, 4, 0)
+    assert E.choose_tiling(1024, 1280, 1280, 160) == (128, 1, 0)
     assert E.choose_splitk(64, 1280, 768, 160) == 1
     for m, n, k in ((256, 1280, 23040), (1024, 640, 5760), (4096, 640, 5760), (1024, 1280, 1280)):
         tm, s, _ = E.choose_tiling(m, n, k, 160)
