@@ -75,8 +75,9 @@ def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> T
     """(tile_m, splitk, tune_flags) for one implicit GEMM, from measurements over every layer shape
     of the B=4 / 512x512 step on MI355X (scripts/op_bench.py, profiles/r01_*_op_bench.txt):
       * K >= 12 tiles: the wave-specialised LDS-DMA ring kernel, 128-row tiles, ONE workgroup per CU;
-        split K only while a slice keeps >= 16 K tiles (8 on the tiny 8x8 / 16x16 grids) and the grid
+        split K only while a slice keeps >= 16 K tiles (8-10 on the small 8x8..32x32 grids) and the grid
         stays near 256 workgroups — the fp32 slabs and the finish kernel cost more than idle CUs below that;
+        with >= 8 tiles per CU (VAE) the ring is kept running over a run of tiles (DADD_TUNE_PERSIST);
       * short K with more 128-row tiles than CUs (qkv, the GEGLU projection at 32x32): the same kernel
         with its ring kept running over a run of output tiles per workgroup (DADD_TUNE_PERSIST);
       * other short-K linears: the register-staged kernel, two workgroups per CU, 64-row tiles when
@@ -90,9 +91,11 @@ def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> T
             return 64, 1, L.TUNE_NODMA | L.TUNE_SHALLOW
         return 128, 1, (L.TUNE_PERSIST if t128 >= 4 * N_CU else 0)
     if nkt >= 12:
-        per = 16 if t128 > 16 else 8
+        if n <= 128 and nkt <= 18:      # VAE 128-channel convs: one column tile, the DMA stream is the longer side
+            return 128, 1, L.TUNE_NODMA
+        per = 16 if t128 > 64 else (10 if t128 > 16 else 8)
         sk = max(1, min(round(N_CU / t128), nkt // per, 32))
-        return 128, sk, 0
+        return 128, sk, (L.TUNE_PERSIST if sk == 1 and t128 >= 8 * N_CU else 0)   # VAE: >= 8 tiles per CU
     if t128 > N_CU:
         return 128, 1, L.TUNE_PERSIST
     return (128 if t128 >= 2 * N_CU else 64), 1, L.TUNE_NODMA
