@@ -141,7 +141,7 @@ def main():
             be.copy_(loop.u.lat_in, lat.to(dev))
             be.zero_(loop.step)
             be.synchronize()
-            be.prof_begin(2)          # exactly igemm_dma_kernel<160,false,false,true>: one row of rocprofv3 --stats
+            be.prof_begin(2)          # exactly conv3x3_halo_kernel: one row of rocprofv3 --stats
             for _ in range(2):
                 loop._one_step(a.steer_scale, False, 1.0)
             st = be.prof_end()
@@ -166,7 +166,7 @@ def main():
                 traffic, traffic_src = dom["traffic_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc)"
             except (OSError, KeyError, ValueError):
                 pass
-            roof = {"bound": "mfma", "kernel": "igemm_dma_kernel<160,false,false,true> (LDS-DMA implicit-GEMM conv/linear)",
+            roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel (3x3 conv, halo-resident LDS-DMA + MFMA, conv_halo.hip)",
                     "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                     "launches_per_step": st["launches"] // 2,

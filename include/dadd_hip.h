@@ -154,7 +154,7 @@ int dadd_graph_launch(void* graph_exec, void* stream);
 int dadd_graph_destroy(void* graph_exec);
 
 /* ---- in-library HIP-event timing of one kernel family (bench.py roofline) -------------------
- * kind 1 = every implicit GEMM, kind 2 = only igemm_dma_kernel<160,false,false,true> (the dominant kernel of
+ * kind 1 = every implicit GEMM, kind 2 = only conv3x3_halo_kernel (the dominant kernel of
  * the UNet step).  While enabled (eager launches only, never during capture) every
  * launch of that family is bracketed by events on its own stream.  dadd_prof_end fills
  * out[0]=launches, out[1]=total ms, out[2]=total algorithmic flop (2*M*N*K). */

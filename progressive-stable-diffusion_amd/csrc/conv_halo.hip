@@ -1,0 +1,293 @@
+// 3x3 / stride-1 / pad-1 convolution with the activation HALO resident in LDS.
+//
+// Why.  The LDS-DMA implicit GEMM (igemm_dma.hip) re-loads the 128-pixel activation tile once per tap:
+// 16 KB of activations + 20 KB of weights per 64-deep K tile.  Its DMA stream is bound by the CU's
+// vector-memory path (~32 B/clk/CU measured, profiles/r01_x_dma_limits.txt), i.e. ~1120 cycles per K tile
+// against 640 cycles of MFMA.  The nine taps of one 64-channel chunk read shifted copies of the same
+// (R+2) x (W+2) pixel halo (R = 128 / W rows of the output tile), so this kernel loads the halo ONCE per
+// chunk (33.8 KB at W = 64, i.e. 3.8 KB per tap instead of 16 KB) and forms the nine A operands by
+// shifted fragment reads: 23.8 KB instead of 36 KB of DMA per K tile.
+//
+// Structure (same tile, MFMA, epilogue and wave specialisation as igemm_dma.hip):
+//   * 128 output pixels (whole image rows) x 160 channels per workgroup, 8 waves: waves 0-3 MFMA,
+//     waves 4-7 DMA; K is walked chunk-major, taps fastest: k = tap * Cin + chunk * 64 + [0, 64);
+//   * LDS: weight ring 4 x 20 KB | halo buffer x 2 (34 KB each) | 4 KB dump for dead DMA slots;
+//     halo pixel p lives at p * 128 B with its eight 16-B chunks XOR-swizzled by (p >> 1) & 7, so a
+//     fragment read of 16 consecutive pixels at any tap shift is bank-conflict free;
+//   * per K tile (one tap) a loader wave issues ONE halo piece of the NEXT chunk (8 pixels x 128 B,
+//     nine slots per chunk; out-of-image pixels use an out-of-range offset = hardware zero fill) and
+//     then its five weight pieces; the counted wait `vmcnt(5)` therefore covers every halo piece and
+//     the weight tile of the next tap; one raw s_barrier per tap;
+//   * fragments of the next tap are prefetched under the MFMAs, except across a chunk boundary, where
+//     the last halo piece of the next chunk is still in flight (one exposed LDS latency per 9 taps).
+// Split-K slices are ranges of chunks (fp32 slabs + splitk_finish_kernel, as for the implicit GEMM).
+#include <cstdlib>
+
+#include "dadd_common.h"
+#include "igemm_args.h"
+#include "igemm_epilogue.h"
+
+namespace {
+
+constexpr int BM = 128, BK = 64, BN = 160;
+constexpr int WN = BN / 2, J = WN / 16, NBJ = BN / 32;
+constexpr int B_BYTES = BN * BK * 2;               // one weight tile
+constexpr int W_RING = 4 * B_BYTES;
+constexpr int HALO_PIECES = 36;                    // 9 slots x 4 loader waves, 8 pixels each
+constexpr int HALO_MAX_PIX = 272;                  // >= (R+2)*(W+2) for W in {16, 32, 64}
+constexpr int HALO_BYTES = HALO_MAX_PIX * 128;
+constexpr int DUMP_OFF = W_RING + 2 * HALO_BYTES;
+constexpr int SMEM_BYTES = DUMP_OFF + 4 * 1024;
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr unsigned OOB = 0x80000000u;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wave_all >= 4;
+  const int wave = wave_all & 3;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+  int mt, nt;
+  tile_decode(p, tile_id, mt, nt);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int z = blockIdx.y;
+  const int Cin = p.C1 + p.C2;
+  const int nchunk = Cin / BK;
+  const int c0 = z * p.kps;                         // p.kps: chunks per K slice for this kernel
+  const int c1 = min(nchunk, c0 + p.kps);
+  const int n_it = (c1 - c0) * 9;
+
+  const int W = p.Wo, H = p.Ho, WH = W + 2;
+  const int R = BM / W;                             // output rows per tile
+  const int HP = (R + 2) * WH;                      // halo pixels
+  const int tpi = (H * W) / BM;                     // tiles per image
+  const int b = mt / tpi;
+  const int y0 = (mt - b * tpi) * R;
+
+  if (loader) {
+    // ---- per-lane DMA state
+    const int lrow = lane >> 3, lch = lane & 7;
+    unsigned hv1[9], hv2[9];                        // halo piece `slot`: byte offset of this lane's 16 B
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      const int pi = s * 4 + wave;
+      const int px = pi * 8 + lrow;
+      const int hy = px / WH, hx = px - hy * WH;
+      const int y = y0 - 1 + hy, x = hx - 1;
+      const bool ok = px < HP && y >= 0 && y < H && x >= 0 && x < W;
+      const int chunk = lch ^ ((px >> 1) & 7);
+      const int pix = (b * H + y) * W + x;
+      hv1[s] = ok ? (unsigned)((pix * p.C1 + chunk * 8) * 2) : OOB;
+      hv2[s] = ok ? (unsigned)((pix * p.C2 + chunk * 8) * 2) : OOB;
+    }
+    const int live_pieces = (HP + 7) >> 3;
+    unsigned w_v[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int row = (j * 4 + wave) * 8 + lrow;
+      const int n = n0 + row;
+      w_v[j] = (n < p.N) ? (unsigned)(((size_t)n * p.K + (lch ^ ((row >> 1) & 7)) * 8) * 2) : OOB;
+    }
+    const size_t pix_total = (size_t)p.B * H * W;
+    const int rec1 = (int)(pix_total * p.C1 * 2), rec2 = (int)(pix_total * p.C2 * 2);
+    const int recW = (int)((size_t)p.N * p.K * 2);
+    const half_t* base2 = p.x2 ? p.x2 : p.x;
+
+    // halo piece `slot` of chunk c -> buffer (c - c0) & 1; dead slots go to the dump area
+    auto issue_halo = [&](int c, int slot) {
+      const bool have = c < c1;
+      const bool second = (c * BK) >= p.C1;
+      const int cb = second ? c * BK - p.C1 : c * BK;
+      const bool live = have && (slot * 4 + wave) < live_pieces;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(second ? base2 : p.x), 0, have ? (second ? rec2 : rec1) : 0, 0x00020000);
+      const int dst = live ? W_RING + ((c - c0) & 1) * HALO_BYTES + (slot * 4 + wave) * 1024
+                           : DUMP_OFF + wave * 1024;
+      const unsigned vo = second ? hv2[slot] : hv1[slot];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + dst), 16, live ? vo : OOB,
+                                               (unsigned)(cb * 2), 0, 0);
+    };
+    // weight tile of local iteration gi (chunk c0 + gi / 9, tap gi % 9) -> ring slot gi & 3
+    int wk_tap = 0, wk_c = c0 * BK, wk_gi = 0;      // cursor of the NEXT weight tile to issue
+    auto issue_w = [&]() {
+      const bool live = wk_gi < n_it;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
+      char* dst = smem + (wk_gi & 3) * B_BYTES + wave * 1024;
+      const unsigned koff = (unsigned)((wk_tap * Cin + wk_c) * 2);
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + j * 4096), 16, w_v[j], koff, 0, 0);
+      ++wk_gi;
+      const int t1 = wk_tap + 1;
+      const int wrap = t1 == 9 ? 1 : 0;
+      wk_tap = wrap ? 0 : t1;
+      wk_c += wrap ? BK : 0;
+    };
+
+    // prologue: the whole halo of the first chunk, then weight tiles 0, 1, 2
+#pragma unroll
+    for (int s = 0; s < 9; ++s) issue_halo(c0, s);
+    issue_w();
+    issue_w();
+    issue_w();
+    wait_vmcnt<NBJ>();                              // everything but weight tile 2
+    __builtin_amdgcn_s_barrier();
+    int cur_c = c0, cur_t = 0;
+    for (int gi = 0; gi < n_it; ++gi) {
+      if (gi > 0) {
+        wait_vmcnt<NBJ>();                          // all but the weight tile issued last iteration
+        __builtin_amdgcn_s_barrier();
+      }
+      // the halo piece FIRST: the next wait (all but the NBJ youngest) then covers it
+      switch (cur_t) {                              // hv1/hv2 stay in registers: constant indices only
+        case 0: issue_halo(cur_c + 1, 0); break;
+        case 1: issue_halo(cur_c + 1, 1); break;
+        case 2: issue_halo(cur_c + 1, 2); break;
+        case 3: issue_halo(cur_c + 1, 3); break;
+        case 4: issue_halo(cur_c + 1, 4); break;
+        case 5: issue_halo(cur_c + 1, 5); break;
+        case 6: issue_halo(cur_c + 1, 6); break;
+        case 7: issue_halo(cur_c + 1, 7); break;
+        default: issue_halo(cur_c + 1, 8); break;
+      }
+      issue_w();                                    // tile gi + 3 -> the slot of tile gi - 1
+      const int t1 = cur_t + 1;
+      const int wrap = t1 == 9 ? 1 : 0;
+      cur_t = wrap ? 0 : t1;
+      cur_c += wrap;
+    }
+    wait_vmcnt<0>();
+    return;
+  }
+
+  // ---- compute waves
+  f4 acc[J][4];
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+  const int fq = lane >> 4;
+  int p0[4];                                        // halo pixel of tap (0, 0) for fragment i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wm * 64 + i * 16 + (lane & 15);
+    const int r = q / W;
+    p0[i] = r * WH + (q - r * W);
+  }
+  const int swb = (wn * WN + (lane & 15));
+  const int fb0 = (swb * 8 + (fq ^ ((swb >> 1) & 7))) * 16;         // weight fragment, K half 0
+  const int fb1 = fb0 ^ 64;                                         // K half 1: chunk index ^ 4
+  // (rows j*16 further down keep the swizzle term: (row + 16 j) >> 1 & 7 == (row >> 1) & 7)
+  auto a_addr = [&](int i, int dt) {                // byte offset inside a halo buffer, K half 0
+    const int px = p0[i] + dt;
+    return px * 128 + ((fq ^ ((px >> 1) & 7)) << 4);
+  };
+
+  __builtin_amdgcn_s_barrier();                     // halo of the first chunk and weight tiles 0, 1 landed
+  __builtin_amdgcn_sched_barrier(0);
+  h8 xa0[4], xa1[4], wb0[J], wb1[J];
+  int aoff[4];                                      // addresses of the CURRENT tap (half 0)
+  {
+    const char* hb = smem + W_RING;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      aoff[i] = a_addr(i, 0);
+      xa0[i] = *reinterpret_cast<const h8*>(hb + aoff[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb0 + j * 2048);
+  }
+  int cur_t = 0, cur_ky = 0, cur_kx = 0, hsel = 0;  // tap of this iteration, halo buffer of this chunk
+  for (int gi = 0; gi < n_it; ++gi) {
+    if (gi > 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* hb = smem + W_RING + hsel * HALO_BYTES;
+    const char* wcur1 = smem + (gi & 3) * B_BYTES + fb1;
+    const char* wnext = smem + ((gi + 1) & 3) * B_BYTES + fb0;
+    if (cur_t == 0 && gi > 0) {                     // first tap of a new chunk: no prefetch was possible
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        aoff[i] = a_addr(i, 0);
+        xa0[i] = *reinterpret_cast<const h8*>(hb + aoff[i]);
+      }
+    }
+    // next tap
+    const int kx1 = cur_kx + 1;
+    const int w3 = kx1 == 3 ? 1 : 0;
+    const int nkx = w3 ? 0 : kx1;
+    const int nky = cur_ky + w3;                    // 3 == chunk boundary
+    const bool same_chunk = nky < 3;
+    const int ndt = nky * WH + nkx;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4 * J; ++k) {               // K half 0; the half-1 fragments stream in behind
+      const int jj = k / 4, ii = k % 4;
+      acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
+      if (k == 0) wb1[0] = *reinterpret_cast<const h8*>(wcur1);
+      else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(hb + (aoff[k - 1] ^ 64));
+      else if (k < 4 + J) wb1[k - 4] = *reinterpret_cast<const h8*>(wcur1 + (k - 4) * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (same_chunk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aoff[i] = a_addr(i, ndt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4 * J; ++k) {               // K half 1; prefetch of the next tap's half 0
+      const int jj = k / 4, ii = k % 4;
+      acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
+      if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(wnext);
+      else if (k <= 4) {
+        if (same_chunk) xa0[k - 1] = *reinterpret_cast<const h8*>(hb + aoff[k - 1]);
+      } else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur_kx = nkx;
+    cur_ky = same_chunk ? nky : 0;
+    cur_t = same_chunk ? cur_t + 1 : 0;
+    hsel = same_chunk ? hsel : hsel ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
+#endif
+}
+
+}  // namespace
+
+int dadd_init_conv_halo() {
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  return DADD_OK;
+}
+
+// Shapes this kernel takes (everything else stays on the implicit GEMM).
+bool dadd_conv_halo_applicable(const IgemmArgs& a, int tile_n) {
+  static const bool off = getenv("DADD_NO_HALO") != nullptr;   // A/B measurements only
+  return !off && a.taps == 9 && a.stride == 1 && a.pad == 1 && !a.ups && tile_n == BN &&
+         a.Hi == a.Ho && a.Wi == a.Wo && (a.Wo == 16 || a.Wo == 32 || a.Wo == 64) &&
+         (a.Ho * a.Wo) % BM == 0 && (BM / a.Wo + 2) * (a.Wo + 2) <= HALO_MAX_PIX &&
+         !(a.flags & (DADD_EPI_GEGLU | DADD_TUNE_PERSIST));
+}
+
+// `a.kps` = chunks per K slice, `a.splitk` = nsplit (set by the caller).
+int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
+  DADD_REQUIRE((size_t)a.B * a.Hi * a.Wi * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2 < 0x7FF00000ull &&
+                   (size_t)a.N * a.K * 2 < 0x7FF00000ull,
+               "conv_halo: operand larger than the 2 GiB buffer window");
+  dim3 grid(a.mtiles * a.ntiles, nsplit);
+  hipLaunchKernelGGL(conv3x3_halo_kernel, grid, dim3(512), SMEM_BYTES, s, a);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}

@@ -238,6 +238,7 @@ int launch2(const IgemmArgs& a, int nsplit, bool deep, hipStream_t s) {
 
 int dadd_init_igemm() {
   int rc = dadd_init_igemm_dma();
+  if (rc == DADD_OK) rc = dadd_init_conv_halo();
   if (rc == DADD_OK) rc = set_attr<128, 128, false>();
   if (rc == DADD_OK) rc = set_attr<128, 128, true>();
   if (rc == DADD_OK) rc = set_attr<128, 160, false>();
@@ -343,12 +344,25 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // persistent ring: a workgroup walks a contiguous run of tiles; with the column tile fastest the run
   // keeps ONE activation row tile (L2-hot after the first tile) and streams the weight tiles
   if (dma && dadd_igemm_dma_persistent(a, nsplit)) a.gm = a.gn = 0;
-  // profiling family 1 = every implicit GEMM; family 2 = exactly igemm_dma_kernel<160, false, false, true>, the
-  // dominant kernel of the UNet step (one row of a rocprofv3 --stats summary)
-  const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && dma && tile_n == 160 && !a.ups &&
-                                            !dadd_igemm_dma_persistent(a, nsplit));
+  // 3x3 / stride 1 on whole-row tiles: the halo-resident kernel (conv_halo.hip); K slices = channel chunks
+  const bool halo = dma && dadd_conv_halo_applicable(a, tile_n);
+  int halo_ns = 1;
+  if (halo) {
+    const int chunks = Cin / BK;
+    int sk = d->splitk > 1 ? d->splitk : 1;
+    if (sk > chunks) sk = chunks;
+    a.kps = (chunks + sk - 1) / sk;
+    halo_ns = (chunks + a.kps - 1) / a.kps;
+    a.splitk = halo_ns;
+    DADD_REQUIRE(halo_ns == 1 || a.partial != nullptr, "igemm: split-K needs a partial buffer");
+  }
+  // profiling family 1 = every implicit GEMM / conv; family 2 = exactly conv3x3_halo_kernel, the dominant
+  // kernel of the UNet step (one row of a rocprofv3 --stats summary)
+  const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && halo);
   if (prof) dadd_prof_pre(s);
-  if (dma)
+  if (halo)
+    rc = dadd_launch_conv_halo(a, halo_ns, s);
+  else if (dma)
     rc = dadd_launch_igemm_dma(a, tile_n, nsplit, s);
   else if (tile_m == 128)
     rc = (tile_n == 160) ? launch<128, 160, false>(a, nsplit, s) : launch2<128, 128>(a, nsplit, deep, s);
@@ -356,11 +370,11 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     rc = (tile_n == 160) ? launch2<64, 160>(a, nsplit, deep, s) : launch2<64, 128>(a, nsplit, deep, s);
   if (prof) dadd_prof_post(s, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (rc != DADD_OK) return rc;
-  if (nsplit > 1 && a.counters == nullptr) {
+  if ((halo ? halo_ns : nsplit) > 1 && a.counters == nullptr) {
     const size_t total = (size_t)a.M * (a.N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, nsplit);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, halo ? halo_ns : nsplit);
     DADD_LAUNCH_CHECK();
   }
   return DADD_OK;

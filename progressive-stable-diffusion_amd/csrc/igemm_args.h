@@ -62,3 +62,6 @@ __device__ __forceinline__ void tile_decode(const IgemmArgs& p, int tile_id, int
 int dadd_init_igemm_dma();
 int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s);
 bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit);
+int dadd_init_conv_halo();
+bool dadd_conv_halo_applicable(const IgemmArgs& a, int tile_n);
+int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s);   // a.kps = chunks per K slice

@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdadd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("igemm.hip", "igemm_dma.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip")
+SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip")
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8

@@ -8,7 +8,7 @@ src=progressive-stable-diffusion_amd/csrc
 for e in 1 2; do
   so=progressive-stable-diffusion_amd/exp/libdadd_exp$e.so
   [ -f "$so" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form=1 \
-    -DDADD_IGEMM_EXP=$e $src/igemm.hip $src/igemm_dma.hip $src/norm.hip $src/attention.hip $src/elementwise.hip $src/api.hip -o "$so" || exit 1
+    -DDADD_IGEMM_EXP=$e $src/igemm.hip $src/igemm_dma.hip $src/conv_halo.hip $src/norm.hip $src/attention.hip $src/elementwise.hip $src/api.hip -o "$so" || exit 1
 done
 for e in 0 1 2; do
   timeout -k 10 200 python scripts/exp_dma_limits.py $e > "$out/exp$e.log" 2>&1; rc=$?

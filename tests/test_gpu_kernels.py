@@ -185,6 +185,26 @@ def test_igemm_persistent_ring(hip, case):
         assert torch.equal(o.cpu(), o2.cpu()), "persistent ring and register-staged kernel must agree bit for bit"
 
 
+@pytest.mark.parametrize("b,h,c1,c2,n,splitk", [(2, 64, 128, 0, 320, 1), (1, 32, 128, 64, 480, 1), (2, 16, 256, 0, 160, 1),
+                                                (1, 64, 64, 0, 160, 1), (2, 32, 320, 320, 320, 2), (3, 16, 640, 0, 320, 5)])
+def test_conv3x3_halo_kernel(hip, b, h, c1, c2, n, splitk):
+    """3x3 / stride 1 / pad 1 on 64-, 32- and 16-wide maps goes to conv3x3_halo_kernel (halo of the 128-pixel
+    tile resident in LDS, nine taps by shifted fragment reads): image borders (zero fill), one and several
+    channel chunks, skip-concat (chunks from two tensors), several column tiles, split-K over chunks; against the
+    torch reference and against the register-staged implicit GEMM (other K order -> tolerance, not bits)."""
+    x = rnd((b, h, h, c1), 80)
+    x2 = rnd((b, h, h, c2), 81) if c2 else None
+    k = 9 * (c1 + c2)
+    w = rnd((n, k), 82, 1 / math.sqrt(k))
+    bias, rowvec, res = rnd((n,), 83, 0.1, F32), rnd((b, n), 84, 0.3, F32), rnd((b, h, h, n), 85)
+    kw = dict(x2=x2, bias=bias, rowvec=rowvec, residual=res, taps=9, pad=1, flags=7, tile_m=128)
+    o, o_ref = run_igemm(hip, x, w, (b, h, h, n), splitk=splitk, in_launch_combine=False, **kw)
+    close(o, o_ref, 3e-3, 2e-3, f"halo conv {b}x{h}x{h} c{c1}+{c2}->{n} sk{splitk}")
+    kw["flags"] = 7 | 32
+    o2, _ = run_igemm(hip, x, w, (b, h, h, n), **kw)
+    close(o, o2, 2e-3, 2e-3, "halo conv vs register-staged implicit GEMM")
+
+
 def test_igemm_geglu(hip):
     from progressive_stable_diffusion_amd.engine import geglu_interleave
     m, c = 300, 320

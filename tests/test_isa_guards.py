@@ -12,7 +12,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "progressive-stable-diffusion_amd", "csrc", "igemm_dma.hip")
+CSRC = os.path.join(ROOT, "progressive-stable-diffusion_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -20,16 +20,20 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "igemm_dma.s"
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                    "--cuda-device-only", "-S", SRC, "-o", str(out)], check=True, capture_output=True, timeout=600)
-    return out.read_text()
+    text = ""
+    for name in ("igemm_dma", "conv_halo"):
+        out = tmp_path_factory.mktemp("isa") / f"{name}.s"
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                        "--cuda-device-only", "-S", os.path.join(CSRC, name + ".hip"), "-o", str(out)],
+                       check=True, capture_output=True, timeout=600)
+        text += out.read_text()
+    return text
 
 
 def _functions(asm_text):
     cur, body, out = None, [], {}
     for line in asm_text.splitlines():
-        m = re.match(r"^(_ZN\S*igemm_dma_kernel\S*):", line)
+        m = re.match(r"^(_ZN\S*(?:igemm_dma_kernel|conv3x3_halo_kernel)\S*):", line)
         if m:
             cur, body = m.group(1), []
         elif line.startswith(".Lfunc_end") and cur:
@@ -41,7 +45,7 @@ def _functions(asm_text):
 
 def test_dma_loads_are_not_in_waterfall_loops(asm):
     funcs = _functions(asm)
-    assert len(funcs) >= 8, sorted(funcs)
+    assert len(funcs) >= 9 and any("halo" in f for f in funcs), sorted(funcs)
     for name, body in funcs.items():
         dma = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l and " lds" in l]
         assert dma, name
@@ -50,10 +54,10 @@ def test_dma_loads_are_not_in_waterfall_loops(asm):
 
 
 def test_no_scratch_and_two_waves_per_simd(asm):
-    meta = re.findall(r"\.name:\s+(\S*igemm_dma_kernel\S*)\s.*?\.private_segment_fixed_size:\s+(\d+).*?"
+    meta = re.findall(r"\.name:\s+(\S*(?:igemm_dma_kernel|conv3x3_halo_kernel)\S*)\s.*?\.private_segment_fixed_size:\s+(\d+).*?"
                       r"\.vgpr_count:\s+(\d+)", asm, flags=re.S)
     assert len(meta) >= 8
     for name, scratch, vgpr in meta:
         assert int(scratch) == 0, (name, scratch)
-        if name.endswith("Lb1EEEv9IgemmArgs"):          # WS = true: 512 threads, two waves per SIMD
+        if name.endswith("Lb1EEEv9IgemmArgs") or "halo" in name:   # 512 threads, two waves per SIMD
             assert int(vgpr) <= 256, (name, vgpr)
