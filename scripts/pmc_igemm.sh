@@ -21,7 +21,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for r in rows:
     k=r["Kernel_Name"]
-    if "igemm" not in k: continue
+    if "igemm" not in k and "halo" not in k: continue
     agg[k.split("(")[0][-40:]][r["Counter_Name"]]+=float(r["Counter_Value"])
     cnt[(k.split("(")[0][-40:], r["Counter_Name"])]+=1
 for k,v in agg.items():
