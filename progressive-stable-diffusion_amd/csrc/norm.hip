@@ -38,18 +38,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
     for (int e = 0; e < 8; ++e) s[u][e] = ss[u][e] = 0.f;
   const int nvec = p.C >> 3;
   if (tr < p.RP) {
-    for (int row = row0 + tr; row < row1; row += p.RP) {
-      const size_t pix = (size_t)b * p.HW + row;
+    // four rows per trip, all loads issued before the first use: one 16-B load in flight per thread
+    // made this pass latency-bound (9.5 us for 10.5 MB)
+    for (int row = row0 + tr; row < row1; row += 4 * p.RP) {
+      h8 xv[4][GN_MAXV];
 #pragma unroll
-      for (int u = 0; u < GN_MAXV; ++u) {
-        const int v = tv + u * p.TV;
-        if (v < nvec) {
-          const h8 x = gn_load(p, pix, v * 8);
+      for (int q = 0; q < 4; ++q) {
+        const int rr = row + q * p.RP;
+        const size_t pix = (size_t)b * p.HW + (rr < row1 ? rr : row);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float f = (float)x[e];
-            s[u][e] += f;
-            ss[u][e] += f * f;
+        for (int u = 0; u < GN_MAXV; ++u) {
+          const int v = tv + u * p.TV;
+          if (v < nvec) xv[q][u] = gn_load(p, pix, v * 8);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (row + q * p.RP >= row1) continue;
+#pragma unroll
+        for (int u = 0; u < GN_MAXV; ++u) {
+          if (tv + u * p.TV < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)xv[q][u][e];
+              s[u][e] += f;
+              ss[u][e] += f * f;
+            }
           }
         }
       }
@@ -67,16 +81,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
     }
   }
   __syncthreads();
-  if (t < p.groups) {
+  {   // group sums: 8 lanes per group (fixed order: lane-strided partials, then a 3-step butterfly)
+    const int g = t >> 3, sub = t & 7;
     float a = 0.f, q = 0.f;
-    for (int r = 0; r < p.RP; ++r)
-      for (int c = t * p.cg; c < (t + 1) * p.cg; ++c) {
+    if (g < p.groups) {
+      const int n = p.RP * p.cg;
+      for (int idx = sub; idx < n; idx += 8) {
+        const int r = idx / p.cg, c = g * p.cg + (idx - r * p.cg);
         a += sm[r * p.C + c];
         q += sm[(p.RP + r) * p.C + c];
       }
-    float* w = p.ws + (((size_t)b * p.nchunk + chunk) * p.groups + t) * 2;
-    w[0] = a;
-    w[1] = q;
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (g < p.groups && sub == 0) {
+      float* w = p.ws + (((size_t)b * p.nchunk + chunk) * p.groups + g) * 2;
+      w[0] = a;
+      w[1] = q;
+    }
   }
 }
 
@@ -158,21 +183,44 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
   const int nvec = p.C >> 3;
   const int row0 = blockIdx.x * p.rows_per_block;
   const int row1 = min(p.HW, row0 + p.rows_per_block);
-  for (int row = row0 + tr; row < row1; row += p.RP) {
-    const size_t pix = (size_t)b * p.HW + row;
+  float sc[GN_MAXV][8], sh[GN_MAXV][8];     // this thread's channels are the same for every row
 #pragma unroll
-    for (int u = 0; u < GN_MAXV; ++u) {
-      const int v = tv + u * p.TV;
-      if (v < nvec) {
-        const h8 x = gn_load(p, pix, v * 8);
-        h8 o;
+  for (int u = 0; u < GN_MAXV; ++u) {
+    const int v = tv + u * p.TV;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)x[e] * scale[v * 8 + e] + shift[v * 8 + e];
-          if (p.silu) f = dadd_silu(f);
-          o[e] = (half_t)f;
+    for (int e = 0; e < 8; ++e) {
+      sc[u][e] = v < nvec ? scale[v * 8 + e] : 0.f;
+      sh[u][e] = v < nvec ? shift[v * 8 + e] : 0.f;
+    }
+  }
+  for (int row = row0 + tr; row < row1; row += 4 * p.RP) {   // four rows in flight per thread
+    h8 xv[4][GN_MAXV];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = row + q * p.RP;
+      const size_t pix = (size_t)b * p.HW + (rr < row1 ? rr : row);
+#pragma unroll
+      for (int u = 0; u < GN_MAXV; ++u)
+        if (tv + u * p.TV < nvec) xv[q][u] = gn_load(p, pix, (tv + u * p.TV) * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = row + q * p.RP;
+      if (rr >= row1) continue;
+      const size_t pix = (size_t)b * p.HW + rr;
+#pragma unroll
+      for (int u = 0; u < GN_MAXV; ++u) {
+        const int v = tv + u * p.TV;
+        if (v < nvec) {
+          h8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)xv[q][u][e] * sc[u][e] + sh[u][e];
+            if (p.silu) f = dadd_silu(f);
+            o[e] = (half_t)f;
+          }
+          *reinterpret_cast<h8*>(p.out + pix * p.C + v * 8) = o;
         }
-        *reinterpret_cast<h8*>(p.out + pix * p.C + v * 8) = o;
       }
     }
   }
