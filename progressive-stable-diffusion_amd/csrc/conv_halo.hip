@@ -12,8 +12,9 @@
 //   * 128 output pixels (whole image rows) x 160 channels per workgroup, 8 waves: waves 0-3 MFMA,
 //     waves 4-7 DMA; K is walked chunk-major, taps fastest: k = tap * Cin + chunk * 64 + [0, 64);
 //   * LDS: weight ring 4 x 20 KB | halo buffer x 2 (34 KB each) | 4 KB dump for dead DMA slots;
-//     halo pixel p lives at p * 128 B with its eight 16-B chunks XOR-swizzled by (p >> 1) & 7, so a
-//     fragment read of 16 consecutive pixels at any tap shift is bank-conflict free;
+//     halo pixel p lives at p * 128 B with its eight 16-B chunks XOR-swizzled by p & 7: a ds_read_b128
+//     fragment read of 16 consecutive pixels starting at ANY pixel (any tap shift) is bank-conflict free
+//     (the (p >> 1) & 7 swizzle of the aligned GEMM tiles is not: 23 % conflict cycles measured);
 //   * per K tile (one tap) a loader wave issues ONE halo piece of the NEXT chunk (8 pixels x 128 B,
 //     nine slots per chunk; out-of-image pixels use an out-of-range offset = hardware zero fill) and
 //     then its five weight pieces; the counted wait `vmcnt(5)` therefore covers every halo piece and
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       const int hy = px / WH, hx = px - hy * WH;
       const int y = y0 - 1 + hy, x = hx - 1;
       const bool ok = px < HP && y >= 0 && y < H && x >= 0 && x < W;
-      const int chunk = lch ^ ((px >> 1) & 7);
+      const int chunk = lch ^ (px & 7);
       const int pix = (b * H + y) * W + x;
       hv1[s] = ok ? (unsigned)((pix * p.C1 + chunk * 8) * 2) : OOB;
       hv2[s] = ok ? (unsigned)((pix * p.C2 + chunk * 8) * 2) : OOB;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
   // (rows j*16 further down keep the swizzle term: (row + 16 j) >> 1 & 7 == (row >> 1) & 7)
   auto a_addr = [&](int i, int dt) {                // byte offset inside a halo buffer, K half 0
     const int px = p0[i] + dt;
-    return px * 128 + ((fq ^ ((px >> 1) & 7)) << 4);
+    return px * 128 + ((fq ^ (px & 7)) << 4);
   };
 
   __builtin_amdgcn_s_barrier();                     // halo of the first chunk and weight tiles 0, 1 landed
