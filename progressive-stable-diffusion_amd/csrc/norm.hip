@@ -1,6 +1,7 @@
 // GroupNorm(+SiLU) over NHWC fp16 with a fused skip-concat, and LayerNorm — HBM-bound kernels:
 // 16-byte loads/stores, fp32 statistics, wavefront-shuffle / LDS reductions, no atomics (results
 // are bit-reproducible run to run).
+#include <cstdlib>
 #include "dadd_common.h"
 
 namespace {
@@ -377,7 +378,8 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   p.stats = ws + (size_t)B * (DADD_GN_MAX_CHUNKS - 1) * groups * 2;   // last chunk slot of the workspace
   p.rows_per_chunk = (HW + nchunk - 1) / nchunk;
   p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
-  const bool fin_in_apply = nchunk <= 64;   // measured: the extra launch only pays on big maps
+  static const int fin_max = getenv("DADD_GN_FIN_MAX") ? atoi(getenv("DADD_GN_FIN_MAX")) : 64;   // A/B only
+  const bool fin_in_apply = nchunk <= fin_max;   // measured: the extra launch only pays on big maps
   p.rows_per_block = (fin_in_apply ? 4 : 8) * p.RP;
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
