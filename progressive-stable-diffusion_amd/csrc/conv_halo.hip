@@ -48,6 +48,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// DEEPQ: a weight tile may stay in flight for THREE tap periods instead of two (the loader's counted wait
+// leaves two groups outstanding; the MFMA waves then read a tile's first weight fragments at the top of
+// its own iteration instead of prefetching them one iteration early).
+template <bool DEEPQ>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -141,13 +145,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     for (int s = 0; s < 9; ++s) issue_halo(c0, s);
     issue_w();
     issue_w();
+    if constexpr (DEEPQ) issue_halo(c1, 0);         // dead slot: every later group is then 1 + NBJ operations
     issue_w();
-    wait_vmcnt<NBJ>();                              // everything but weight tile 2
+    if constexpr (DEEPQ) wait_vmcnt<2 * NBJ + 1>(); // halo + weight tile 0
+    else wait_vmcnt<NBJ>();                         // everything but weight tile 2
     __builtin_amdgcn_s_barrier();
     int cur_c = c0, cur_t = 0;
     for (int gi = 0; gi < n_it; ++gi) {
       if (gi > 0) {
-        wait_vmcnt<NBJ>();                          // all but the weight tile issued last iteration
+        if constexpr (DEEPQ) {
+          // tile gi landed; the groups of the last two iterations (halo piece + 5 weight pieces each) may
+          // be in flight — except at a chunk boundary, where last iteration's halo piece is needed now
+          if (cur_t == 0) wait_vmcnt<NBJ>();
+          else wait_vmcnt<2 * NBJ + 2>();
+        } else {
+          wait_vmcnt<NBJ>();                        // all but the weight tile issued last iteration
+        }
         __builtin_amdgcn_s_barrier();
       }
       // the halo piece FIRST: the next wait (all but the NBJ youngest) then covers it
@@ -216,6 +229,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     const char* hb = smem + W_RING + hsel * HALO_BYTES;
     const char* wcur1 = smem + (gi & 3) * B_BYTES + fb1;
     const char* wnext = smem + ((gi + 1) & 3) * B_BYTES + fb0;
+    if constexpr (DEEPQ) {
+      if (gi > 0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + (gi & 3) * B_BYTES + fb0 + j * 2048);
+      }
+    }
     if (cur_t == 0 && gi > 0) {                     // first tap of a new chunk: no prefetch was possible
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -249,10 +268,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     for (int k = 0; k < 4 * J; ++k) {               // K half 1; prefetch of the next tap's half 0
       const int jj = k / 4, ii = k % 4;
       acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
-      if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(wnext);
+      if (k == 0) { if constexpr (!DEEPQ) wb0[0] = *reinterpret_cast<const h8*>(wnext); }
       else if (k <= 4) {
         if (same_chunk) xa0[k - 1] = *reinterpret_cast<const h8*>(hb + aoff[k - 1]);
-      } else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048);
+      } else if (k < 4 + J) { if constexpr (!DEEPQ) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048); }
       __builtin_amdgcn_sched_barrier(0);
     }
     cur_kx = nkx;
@@ -268,7 +287,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
 }  // namespace
 
 int dadd_init_conv_halo() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
   return DADD_OK;
 }
@@ -288,7 +309,9 @@ int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "conv_halo: operand larger than the 2 GiB buffer window");
   dim3 grid(a.mtiles * a.ntiles, nsplit);
-  hipLaunchKernelGGL(conv3x3_halo_kernel, grid, dim3(512), SMEM_BYTES, s, a);
+  static const bool deepq = getenv("DADD_HALO_DEEPQ") ? atoi(getenv("DADD_HALO_DEEPQ")) != 0 : false;   // A/B
+  if (deepq) hipLaunchKernelGGL(conv3x3_halo_kernel<true>, grid, dim3(512), SMEM_BYTES, s, a);
+  else hipLaunchKernelGGL(conv3x3_halo_kernel<false>, grid, dim3(512), SMEM_BYTES, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
