@@ -28,6 +28,19 @@
 #include "igemm_args.h"
 #include "igemm_epilogue.h"
 
+// Diagnostic build only (-DDADD_IGEMM_EXP=3, scripts/exp_stamps.sh): s_memtime stamps around the waits of
+// one MFMA wave and one loader wave per workgroup, summed into p.partial[workgroup][8] (as uint64 counts).
+#ifndef DADD_IGEMM_EXP
+#define DADD_IGEMM_EXP 0
+#endif
+#if DADD_IGEMM_EXP == 3
+#define DADD_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define DADD_ACC(dst, a, b) dst += (b) - (a)
+#else
+#define DADD_STAMP(var)
+#define DADD_ACC(dst, a, b)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BK = 64, BN = 160;
@@ -151,7 +164,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     else wait_vmcnt<NBJ>();                         // everything but weight tile 2
     __builtin_amdgcn_s_barrier();
     int cur_c = c0, cur_t = 0;
+    [[maybe_unused]] unsigned long long st_wait = 0, st_bar = 0, st_issue = 0;
+    DADD_STAMP(l_begin);
     for (int gi = 0; gi < n_it; ++gi) {
+      DADD_STAMP(l0);
       if (gi > 0) {
         if constexpr (DEEPQ) {
           // tile gi landed; the groups of the last two iterations (halo piece + 5 weight pieces each) may
@@ -161,8 +177,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
         } else {
           wait_vmcnt<NBJ>();                        // all but the weight tile issued last iteration
         }
-        __builtin_amdgcn_s_barrier();
       }
+      DADD_STAMP(l1);
+      if (gi > 0) __builtin_amdgcn_s_barrier();
+      DADD_STAMP(l2);
       // the halo piece FIRST: the next wait (all but the NBJ youngest) then covers it
       switch (cur_t) {                              // hv1/hv2 stay in registers: constant indices only
         case 0: issue_halo(cur_c + 1, 0); break;
@@ -180,8 +198,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       const int wrap = t1 == 9 ? 1 : 0;
       cur_t = wrap ? 0 : t1;
       cur_c += wrap;
+      DADD_STAMP(l3);
+      DADD_ACC(st_wait, l0, l1);
+      DADD_ACC(st_bar, l1, l2);
+      DADD_ACC(st_issue, l2, l3);
     }
     wait_vmcnt<0>();
+#if DADD_IGEMM_EXP == 3
+    if (wave == 0 && lane == 0 && p.partial && blockIdx.y == 0) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.partial) + (size_t)blockIdx.x * 8;
+      o[4] = st_wait; o[5] = st_bar; o[6] = st_issue; o[7] = __builtin_amdgcn_s_memtime() - l_begin;
+    }
+#endif
     return;
   }
 
@@ -223,8 +251,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb0 + j * 2048);
   }
   int cur_t = 0, cur_ky = 0, cur_kx = 0, hsel = 0;  // tap of this iteration, halo buffer of this chunk
+  [[maybe_unused]] unsigned long long sc_bar = 0, sc_h0 = 0, sc_h1 = 0;
+  DADD_STAMP(c_begin);
   for (int gi = 0; gi < n_it; ++gi) {
+    DADD_STAMP(c0s);
     if (gi > 0) __builtin_amdgcn_s_barrier();
+    DADD_STAMP(c1s);
     __builtin_amdgcn_sched_barrier(0);
     const char* hb = smem + W_RING + hsel * HALO_BYTES;
     const char* wcur1 = smem + (gi & 3) * B_BYTES + fb1;
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
 #pragma unroll
       for (int i = 0; i < 4; ++i) aoff[i] = a_addr(i, ndt);
     }
+    DADD_STAMP(c2s);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 4 * J; ++k) {               // K half 1; prefetch of the next tap's half 0
@@ -279,7 +312,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     cur_t = same_chunk ? cur_t + 1 : 0;
     hsel = same_chunk ? hsel : hsel ^ 1;
     __builtin_amdgcn_sched_barrier(0);
+    DADD_STAMP(c3s);
+    DADD_ACC(sc_bar, c0s, c1s);
+    DADD_ACC(sc_h0, c1s, c2s);
+    DADD_ACC(sc_h1, c2s, c3s);
   }
+#if DADD_IGEMM_EXP == 3
+  if (wave == 0 && lane == 0 && p.partial && blockIdx.y == 0) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.partial) + (size_t)blockIdx.x * 8;
+    o[0] = sc_bar; o[1] = sc_h0; o[2] = sc_h1; o[3] = __builtin_amdgcn_s_memtime() - c_begin;
+  }
+#endif
   igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
 #endif
 }

@@ -59,6 +59,23 @@ __device__ __forceinline__ float dadd_gelu(float x) {
   const float erf_abs = fmaf(-p * t, e, 1.0f);           // erf(|x|/sqrt2)
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
+// Two at a time on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: full rate on two lanes' worth of data per
+// instruction) — same formula and rounding order per element as dadd_gelu, transcendentals stay scalar.
+typedef float dadd_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dadd_f2 dadd_gelu2(dadd_f2 x) {
+  const dadd_f2 one = {1.0f, 1.0f};
+  const dadd_f2 z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const dadd_f2 d = __builtin_elementwise_fma(dadd_f2{0.3275911f, 0.3275911f}, z, one);
+  const dadd_f2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  dadd_f2 p = __builtin_elementwise_fma(dadd_f2{1.061405429f, 1.061405429f}, t, dadd_f2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, dadd_f2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, dadd_f2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, dadd_f2{0.254829592f, 0.254829592f});
+  const dadd_f2 a = -z * z * 1.4426950408889634f;
+  const dadd_f2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const dadd_f2 erf_abs = __builtin_elementwise_fma(-p * t, e, one);
+  return 0.5f * x * (one + __builtin_elementwise_copysign(erf_abs, x));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -79,9 +79,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
             gv += *reinterpret_cast<const f4*>(p.bias + ng);
           }
           const int no = (n0 >> 1) + wn * 32 + j * 16 + g * 4;
-          h4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(hv[r] * dadd_gelu(gv[r]));
+          const dadd_f2 g01 = dadd_gelu2(dadd_f2{gv[0], gv[1]}), g23 = dadd_gelu2(dadd_f2{gv[2], gv[3]});
+          const h4 o = {(half_t)(hv[0] * g01[0]), (half_t)(hv[1] * g01[1]), (half_t)(hv[2] * g23[0]),
+                        (half_t)(hv[3] * g23[1])};
           *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + no) = o;
         }
       }
