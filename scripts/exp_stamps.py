@@ -22,11 +22,11 @@ for b, side, cin, cout in ((4, 64, 640, 640), (4, 64, 320, 320), (4, 32, 640, 64
     w = be.to_device((torch.randn(cout, k, generator=g) / math.sqrt(k)).half())
     out = be.zeros((b, side, side, cout), torch.float16)
     nwg = (b * side * side // 128) * (cout // 160)
-    stamps = be.zeros((nwg * 16,), torch.float32)           # 8 x uint64 per workgroup
+    stamps = be.zeros((max(nwg * 16, b * side * side * cout),), torch.float32)   # 8 x uint64 per workgroup (sized as a split-K slab)
     for _ in range(3):
         be.igemm(x, w, out, taps=9, pad=1, splitk=1, partial=stamps, tile_m=128)
     be.synchronize()
-    s = stamps.view(torch.int64).view(nwg, 8).double().cpu()
+    s = stamps[:nwg * 16].view(torch.int64).view(nwg, 8).double().cpu()
     m = s.mean(0)
     nit = k // 64
     print(f"conv {b}x{side}x{side} {cin}->{cout}: {nit} taps x chunks per workgroup, stamps in s_memtime ticks (shader-clock cycles)")
