@@ -61,10 +61,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// DEEPQ: a weight tile may stay in flight for THREE tap periods instead of two (the loader's counted wait
-// leaves two groups outstanding; the MFMA waves then read a tile's first weight fragments at the top of
-// its own iteration instead of prefetching them one iteration early).
-template <bool DEEPQ>
+// REGST: after the prologue the loader waves stage through REGISTERS — buffer_load_dwordx4 into VGPRs two
+// taps ahead, ds_write_b128 into the ring / halo slot when it frees — instead of LDS-DMA.  In-kernel stamps
+// (profiles/r01_zi_stamps_conv_halo.txt) show that an LDS-DMA instruction costs its wave ~115 cycles at issue and
+// that this time is taken from the MFMA wave on the same SIMD (per tap: 640 cycles of MFMA + ~690 of DMA issue,
+// no waiting at the barrier on either side); plain loads + LDS writes issue in a fraction of that, the loaders'
+// idle VGPRs hide the memory latency, and the compiler's own counted waits order load -> store.
+template <bool REGST>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -158,28 +161,101 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     for (int s = 0; s < 9; ++s) issue_halo(c0, s);
     issue_w();
     issue_w();
-    if constexpr (DEEPQ) issue_halo(c1, 0);         // dead slot: every later group is then 1 + NBJ operations
     issue_w();
-    if constexpr (DEEPQ) wait_vmcnt<2 * NBJ + 1>(); // halo + weight tile 0
+    if constexpr (REGST) wait_vmcnt<0>();
     else wait_vmcnt<NBJ>();                         // everything but weight tile 2
     __builtin_amdgcn_s_barrier();
     int cur_c = c0, cur_t = 0;
     [[maybe_unused]] unsigned long long st_wait = 0, st_bar = 0, st_issue = 0;
     DADD_STAMP(l_begin);
+    if constexpr (REGST) {
+      // ---- register-staged stream.  Group g = {halo piece (chunk(g) + 1, slot t(g)), weight tile g + 3}; it is
+      // LOADED during iteration g - 2 and STORED to LDS during iteration g (after that iteration's barrier, when
+      // the slot of tile g - 1 is free).  Three register groups, the loop is unrolled by 3 (n_it = 9 x chunks).
+      typedef unsigned u4v __attribute__((ext_vector_type(4)));
+      struct Grp { u4v h; u4v w[NBJ]; };
+      int ld_c = c0, ld_t = 0;                      // load-side cursor (group to load next)
+      // the halo source offset is computed on the fly from a running (row, column) of the lane's pixel:
+      // indexing the nine precomputed offsets with a runtime slot puts the array in scratch, and the
+      // scratch load's vmcnt wait drains the whole prefetch queue
+      const int px0 = wave * 8 + lrow;              // this lane's pixel in slot 0; slot s adds 32 pixels
+      const int hy0 = px0 / WH, hx0 = px0 - hy0 * WH;
+      const int sdy = 32 / WH, sdx = 32 - sdy * WH;
+      const int hchunk = (lch ^ lrow) * 8;          // (px & 7) == lrow for every slot
+      int l_px = px0, l_hy = hy0, l_hx = hx0;
+      auto load_halo = [&](int c) -> u4v {
+        const bool have = c < c1;
+        const bool second = (c * BK) >= p.C1;
+        const int cb = second ? c * BK - p.C1 : c * BK;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(second ? base2 : p.x), 0, have ? (second ? rec2 : rec1) : 0, 0x00020000);
+        const int y = y0 - 1 + l_hy, x = l_hx - 1;
+        const bool ok = l_px < HP && y >= 0 && y < H && x >= 0 && x < W;
+        const int pix = (b * H + y) * W + x;
+        const unsigned vo = ok ? (unsigned)((pix * (second ? p.C2 : p.C1) + hchunk) * 2) : OOB;
+        const u4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)(cb * 2), 0);
+        const bool last = ld_t == 8;                // next slot (selects only)
+        const int nx = l_hx + sdx, carry = nx >= WH ? 1 : 0;
+        l_px = last ? px0 : l_px + 32;
+        l_hx = last ? hx0 : nx - (carry ? WH : 0);
+        l_hy = last ? hy0 : l_hy + sdy + carry;
+        return v;
+      };
+      auto load_group = [&](Grp& g) {
+        g.h = load_halo(ld_c + 1);
+        const bool live = wk_gi < n_it;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, live ? recW : 0, 0x00020000);
+        const unsigned koff = (unsigned)((wk_tap * Cin + wk_c) * 2);
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) g.w[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, w_v[j], koff, 0);
+        ++wk_gi;
+        const int w1 = wk_tap + 1, ww = w1 == 9 ? 1 : 0;
+        wk_tap = ww ? 0 : w1;
+        wk_c += ww ? BK : 0;
+        const int l1 = ld_t + 1, lw = l1 == 9 ? 1 : 0;
+        ld_t = lw ? 0 : l1;
+        ld_c += lw;
+      };
+      int st_wgi = 3;                               // weight tile the next stored group carries
+      auto store_group = [&](const Grp& g) {        // store-side cursor = (cur_c, cur_t)
+        const int pi = cur_t * 4 + wave;
+        const bool live = (cur_c + 1) < c1 && pi < live_pieces;
+        const int lmask = live ? -1 : 0;            // mask arithmetic: a branch here splits the step
+        const int hdst = ((W_RING + ((cur_c + 1 - c0) & 1) * HALO_BYTES + pi * 1024) & lmask) |
+                         ((DUMP_OFF + wave * 1024) & ~lmask);
+        *reinterpret_cast<u4v*>(smem + hdst + lane * 16) = g.h;
+        char* wdst = smem + (st_wgi & 3) * B_BYTES + wave * 1024 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) *reinterpret_cast<u4v*>(wdst + j * 4096) = g.w[j];
+        ++st_wgi;
+        const int t1 = cur_t + 1, wrap = t1 == 9 ? 1 : 0;
+        cur_t = wrap ? 0 : t1;
+        cur_c += wrap;
+      };
+      Grp ga, gb, gc;
+      load_group(ga);                               // groups 0 and 1 in flight before the loop
+      load_group(gb);
+      auto step = [&](const Grp& st, Grp& ld) {     // branch-free: the compiler's counted vmcnt stays exact
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last iteration's LDS writes are done
+        __builtin_amdgcn_s_barrier();
+        store_group(st);                            // the compiler's counted vmcnt waits are exact here (11..6)
+        __builtin_amdgcn_sched_barrier(0);          // keep the new loads behind the stores (and the wait exact)
+        load_group(ld);                             // group gi + 2
+      };
+      for (int gi = 0; gi < n_it; gi += 3) {
+        step(ga, gc);
+        step(gb, ga);
+        step(gc, gb);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      return;
+    }
     for (int gi = 0; gi < n_it; ++gi) {
       DADD_STAMP(l0);
-      if (gi > 0) {
-        if constexpr (DEEPQ) {
-          // tile gi landed; the groups of the last two iterations (halo piece + 5 weight pieces each) may
-          // be in flight — except at a chunk boundary, where last iteration's halo piece is needed now
-          if (cur_t == 0) wait_vmcnt<NBJ>();
-          else wait_vmcnt<2 * NBJ + 2>();
-        } else {
-          wait_vmcnt<NBJ>();                        // all but the weight tile issued last iteration
-        }
-      }
+      wait_vmcnt<NBJ>();                            // all but the weight tile issued last iteration
       DADD_STAMP(l1);
-      if (gi > 0) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       DADD_STAMP(l2);
       // the halo piece FIRST: the next wait (all but the NBJ youngest) then covers it
       switch (cur_t) {                              // hv1/hv2 stay in registers: constant indices only
@@ -255,18 +331,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
   DADD_STAMP(c_begin);
   for (int gi = 0; gi < n_it; ++gi) {
     DADD_STAMP(c0s);
-    if (gi > 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                   // one barrier per tap on both sides (also for gi == 0)
     DADD_STAMP(c1s);
     __builtin_amdgcn_sched_barrier(0);
     const char* hb = smem + W_RING + hsel * HALO_BYTES;
     const char* wcur1 = smem + (gi & 3) * B_BYTES + fb1;
     const char* wnext = smem + ((gi + 1) & 3) * B_BYTES + fb0;
-    if constexpr (DEEPQ) {
-      if (gi > 0) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + (gi & 3) * B_BYTES + fb0 + j * 2048);
-      }
-    }
     if (cur_t == 0 && gi > 0) {                     // first tap of a new chunk: no prefetch was possible
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -301,10 +371,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     for (int k = 0; k < 4 * J; ++k) {               // K half 1; prefetch of the next tap's half 0
       const int jj = k / 4, ii = k % 4;
       acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
-      if (k == 0) { if constexpr (!DEEPQ) wb0[0] = *reinterpret_cast<const h8*>(wnext); }
+      if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(wnext);
       else if (k <= 4) {
         if (same_chunk) xa0[k - 1] = *reinterpret_cast<const h8*>(hb + aoff[k - 1]);
-      } else if (k < 4 + J) { if constexpr (!DEEPQ) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048); }
+      } else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048);
       __builtin_amdgcn_sched_barrier(0);
     }
     cur_kx = nkx;
@@ -352,8 +422,8 @@ int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "conv_halo: operand larger than the 2 GiB buffer window");
   dim3 grid(a.mtiles * a.ntiles, nsplit);
-  static const bool deepq = getenv("DADD_HALO_DEEPQ") ? atoi(getenv("DADD_HALO_DEEPQ")) != 0 : false;   // A/B
-  if (deepq) hipLaunchKernelGGL(conv3x3_halo_kernel<true>, grid, dim3(512), SMEM_BYTES, s, a);
+  static const bool regst = getenv("DADD_HALO_REGST") ? atoi(getenv("DADD_HALO_REGST")) != 0 : true;   // A/B
+  if (regst) hipLaunchKernelGGL(conv3x3_halo_kernel<true>, grid, dim3(512), SMEM_BYTES, s, a);
   else hipLaunchKernelGGL(conv3x3_halo_kernel<false>, grid, dim3(512), SMEM_BYTES, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
