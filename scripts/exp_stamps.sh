@@ -6,4 +6,3 @@ src=progressive-stable-diffusion_amd/csrc
   $src/igemm.hip $src/igemm_dma.hip $src/conv_halo.hip $src/norm.hip $src/attention.hip $src/elementwise.hip $src/api.hip \
   -o progressive-stable-diffusion_amd/exp/libdadd_exp3.so > "$out/build.log" 2>&1 || { tail "$out/build.log"; exit 1; }
 timeout -k 10 200 python scripts/exp_stamps.py > "$out/stamps.log" 2>&1; echo "rc=$?"; grep -v amdgpu.ids "$out/stamps.log"
-DADD_HALO_REGST=0 timeout -k 10 200 python scripts/exp_stamps.py > "$out/stamps_dma.log" 2>&1; echo "dma rc=$?"; grep -v amdgpu.ids "$out/stamps_dma.log"
