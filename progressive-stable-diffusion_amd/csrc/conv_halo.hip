@@ -14,11 +14,10 @@
 //     halo pixel p lives at p * 128 B with its eight 16-B chunks XOR-swizzled by p & 7: a ds_read_b128
 //     fragment read of 16 consecutive pixels starting at ANY pixel (any tap shift) is bank-conflict free
 //     (the (p >> 1) & 7 swizzle of the aligned GEMM tiles is not: 23 % conflict cycles measured);
-//   * loader waves stage through REGISTERS: buffer_load_dwordx4 into VGPRs two taps ahead (the loaders'
-//     otherwise idle registers hide the memory latency; out-of-image pixels use an out-of-range offset =
-//     hardware zero fill), ds_write_b128 into the ring / halo slot once the tap that frees it has passed;
-//     the compiler's own counted vmcnt waits order load -> store, one `lgkmcnt(0)` + raw s_barrier per tap
-//     orders store -> fragment read.  (The first version used LDS-DMA here; same speed, see DESIGN.md.)
+//   * loader waves move data by LDS-DMA (buffer_load_dwordx4 ... offen lds, 8 pixels x 128 B or 8 weight rows
+//     per instruction; out-of-image pixels use an out-of-range offset = hardware zero fill): per tap two halo
+//     slots of the NEXT chunk and then the five weight pieces of tap + 3, behind one counted `vmcnt(5)` and one
+//     raw s_barrier per tap;
 //   * the halo of chunk c+1 is written during taps 0..7 of chunk c (two pieces at tap 7), so it is complete
 //     one tap before it is needed and the MFMA loop is branch-free: every tap prefetches the next tap's
 //     fragments under its MFMAs, also across chunk boundaries.
@@ -31,7 +30,7 @@
 
 // Diagnostic builds only (the product library is built without the macro): 3 = s_memtime stamps around the
 // barrier and the two K halves of one MFMA wave per workgroup, summed into p.partial[workgroup][8] (uint64);
-// 4 / 5 / 6 = loader waves without LDS writes / without global loads / without both (results are garbage).
+// 5 / 6 = loader waves without their DMA stream (results are garbage).
 #ifndef DADD_IGEMM_EXP
 #define DADD_IGEMM_EXP 0
 #endif
@@ -54,7 +53,6 @@ constexpr int HALO_BYTES = HALO_MAX_PIX * 128;
 constexpr int DUMP_OFF = W_RING + 2 * HALO_BYTES;
 constexpr int SMEM_BYTES = DUMP_OFF + 4 * 1024;
 constexpr bool DO_LOAD = DADD_IGEMM_EXP != 5 && DADD_IGEMM_EXP != 6;
-constexpr bool DO_STORE = DADD_IGEMM_EXP != 4 && DADD_IGEMM_EXP != 6;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -154,81 +152,50 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       ++wk_gi;
       ++wk_tap;                                     // taps 0, 1, 2 of the first chunk
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");   // everything but weight tile 2
     __builtin_amdgcn_s_barrier();
 
-    // ---- register-staged stream.  Group g = {halo pieces of chunk(g) + 1 that tap t(g) carries, weight tile
-    // g + 3}; it is LOADED during iteration g - 2 and STORED to LDS during iteration g (after that iteration's
-    // barrier, when the ring slot of tile g - 1 is free).  Tap t carries halo piece t (t <= 7), tap 7 also
-    // piece 8, tap 8 none.  Three register groups, the loop is unrolled by 3 (n_it = 9 x chunks).
-    struct Grp { u4v h[2]; u4v w[NBJ]; };
-    int ld_c = c0, ld_t = 0;                        // load-side cursor
-    auto load_group = [&](Grp& g) {
+    // ---- LDS-DMA stream.  Iteration g (after its barrier, when the ring slot of tile g - 1 is free) issues the
+    // halo pieces of chunk(g) + 1 that tap t(g) carries — piece t for t <= 7, at tap 7 also piece 8, dead slots
+    // go to the dump area so that every iteration issues the same 2 + NBJ instructions — and THEN weight tile
+    // g + 3: the counted wait "all but the NBJ youngest" at the top of the next iteration therefore covers
+    // every halo piece and weight tile g + 1.
+    // (A register-staged variant — buffer_load into VGPRs two taps ahead, ds_write_b128 — measured slower:
+    // 171 vs 142 us on 16384x640x5760; its loaders became the critical path)
+    int cur_c = c0, cur_t = 0;
+    auto halo_dst = [&](int piece_slot, bool take) {
+      const int pi = piece_slot * 4 + wave;
+      const int lmask = (take && (cur_c + 1) < c1 && pi < live_pieces) ? -1 : 0;   // mask arithmetic, no branch
+      return ((W_RING + ((cur_c + 1 - c0) & 1) * HALO_BYTES + pi * 1024) & lmask) | ((DUMP_OFF + wave * 1024) & ~lmask);
+    };
+    for (int gi = 0; gi < n_it; ++gi) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");
+      __builtin_amdgcn_s_barrier();
       __amdgpu_buffer_rsrc_t rs;
       unsigned vo, so;
-      halo_src(ld_c + 1, ld_t <= 7, rs, vo, so);
-      g.h[0] = u4v{vo, so, 0u, 0u};
-      if constexpr (DO_LOAD) g.h[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
-      halo_src(ld_c + 1, ld_t == 7, rs, vo, so);
-      g.h[1] = u4v{vo, so, 0u, 0u};
-      if constexpr (DO_LOAD) g.h[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+      halo_src(cur_c + 1, cur_t <= 7, rs, vo, so);
+      if constexpr (DO_LOAD)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + halo_dst(cur_t, cur_t <= 7)), 16, vo, so, 0, 0);
+      halo_src(cur_c + 1, cur_t == 7, rs, vo, so);
+      if constexpr (DO_LOAD)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + halo_dst(8, cur_t == 7)), 16, vo, so, 0, 0);
       const __amdgpu_buffer_rsrc_t rw =
           __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wk_gi < n_it ? recW : 0, 0x00020000);
+      char* wdst = smem + (wk_gi & 3) * B_BYTES + wave * 1024;
       const unsigned koff = (unsigned)((wk_tap * Cin + wk_c) * 2);
 #pragma unroll
-      for (int j = 0; j < NBJ; ++j) {
-        g.w[j] = u4v{koff, w_v[j], 0u, 0u};
-        if constexpr (DO_LOAD) g.w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_v[j], koff, 0);
-      }
+      for (int j = 0; j < NBJ; ++j)
+        if constexpr (DO_LOAD)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(wdst + j * 4096), 16, w_v[j], koff, 0, 0);
       ++wk_gi;
       const int w1 = wk_tap + 1, ww = w1 == 9 ? 1 : 0;
       wk_tap = ww ? 0 : w1;
       wk_c += ww ? BK : 0;
-      const int l1 = ld_t + 1, lw = l1 == 9 ? 1 : 0;
-      ld_t = lw ? 0 : l1;
-      ld_c += lw;
-    };
-    int st_c = c0, st_t = 0, st_wgi = 3;            // store-side cursor; weight tile the next stored group carries
-    auto halo_dst = [&](int piece_slot, bool take) {
-      const int pi = piece_slot * 4 + wave;
-      const int lmask = (take && (st_c + 1) < c1 && pi < live_pieces) ? -1 : 0;   // mask arithmetic, no branch
-      return ((W_RING + ((st_c + 1 - c0) & 1) * HALO_BYTES + pi * 1024) & lmask) | ((DUMP_OFF + wave * 1024) & ~lmask);
-    };
-    auto store_group = [&](const Grp& g) {
-      const int d0 = halo_dst(st_t, st_t <= 7), d1 = halo_dst(8, st_t == 7);
-      char* wdst = smem + (st_wgi & 3) * B_BYTES + wave * 1024 + lane * 16;
-      if constexpr (DO_STORE) {
-        *reinterpret_cast<u4v*>(smem + d0 + lane * 16) = g.h[0];
-        *reinterpret_cast<u4v*>(smem + d1 + lane * 16) = g.h[1];
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) *reinterpret_cast<u4v*>(wdst + j * 4096) = g.w[j];
-      } else {                                      // keep the loads alive
-        unsigned a = g.h[0][0] ^ g.h[1][1];
-#pragma unroll
-        for (int j = 0; j < NBJ; ++j) a ^= g.w[j][0] ^ g.w[j][3];
-        if (a == 0x12345678u) *reinterpret_cast<unsigned*>(smem + d0 + d1) = a;
-      }
-      ++st_wgi;
-      const int t1 = st_t + 1, wrap = t1 == 9 ? 1 : 0;
-      st_t = wrap ? 0 : t1;
-      st_c += wrap;
-    };
-    Grp ga, gb, gc;
-    load_group(ga);                                 // groups 0 and 1 in flight before the loop
-    load_group(gb);
-    auto step = [&](const Grp& st, Grp& ld) {       // branch-free: the compiler's counted vmcnt stays exact
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last iteration's LDS writes are done
-      __builtin_amdgcn_s_barrier();
-      store_group(st);
-      __builtin_amdgcn_sched_barrier(0);            // keep the new loads behind the stores
-      load_group(ld);                               // group gi + 2
-    };
-    for (int gi = 0; gi < n_it; gi += 3) {
-      step(ga, gc);
-      step(gb, ga);
-      step(gc, gb);
+      const int t1 = cur_t + 1, wrap = t1 == 9 ? 1 : 0;
+      cur_t = wrap ? 0 : t1;
+      cur_c += wrap;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
 
