@@ -15,12 +15,11 @@
 //     fragment read of 16 consecutive pixels starting at ANY pixel (any tap shift) is bank-conflict free
 //     (the (p >> 1) & 7 swizzle of the aligned GEMM tiles is not: 23 % conflict cycles measured);
 //   * loader waves move data by LDS-DMA (buffer_load_dwordx4 ... offen lds, 8 pixels x 128 B or 8 weight rows
-//     per instruction; out-of-image pixels use an out-of-range offset = hardware zero fill): per tap two halo
-//     slots of the NEXT chunk and then the five weight pieces of tap + 3, behind one counted `vmcnt(5)` and one
+//     per instruction; out-of-image pixels use an out-of-range offset = hardware zero fill): per tap one halo
+//     piece of the NEXT chunk and then the five weight pieces of tap + 3, behind one counted `vmcnt(5)` and one
 //     raw s_barrier per tap;
-//   * the halo of chunk c+1 is written during taps 0..7 of chunk c (two pieces at tap 7), so it is complete
-//     one tap before it is needed and the MFMA loop is branch-free: every tap prefetches the next tap's
-//     fragments under its MFMAs, also across chunk boundaries.
+//   * the MFMA loop is branch-free: every tap prefetches the next tap's fragments under its MFMAs, also across
+//     chunk boundaries (the pixels tap (0, 0) needs are in the halo pieces issued during taps 0..4).
 // Split-K slices are ranges of chunks (fp32 slabs + splitk_finish_kernel, as for the implicit GEMM).
 #include <cstdlib>
 
@@ -155,13 +154,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");   // everything but weight tile 2
     __builtin_amdgcn_s_barrier();
 
-    // ---- LDS-DMA stream.  Iteration g (after its barrier, when the ring slot of tile g - 1 is free) issues the
-    // halo pieces of chunk(g) + 1 that tap t(g) carries — piece t for t <= 7, at tap 7 also piece 8, dead slots
-    // go to the dump area so that every iteration issues the same 2 + NBJ instructions — and THEN weight tile
-    // g + 3: the counted wait "all but the NBJ youngest" at the top of the next iteration therefore covers
-    // every halo piece and weight tile g + 1.
-    // (A register-staged variant — buffer_load into VGPRs two taps ahead, ds_write_b128 — measured slower:
-    // 171 vs 142 us on 16384x640x5760; its loaders became the critical path)
+    // ---- LDS-DMA stream.  Iteration g (after its barrier, when the ring slot of tile g - 1 is free) issues halo
+    // piece t(g) of chunk(g) + 1 and THEN weight tile g + 3: the counted wait "all but the NBJ youngest" at the
+    // top of the next iteration therefore covers every halo piece and weight tile g + 1.  The last piece of a
+    // halo lands one tap after its chunk started, which is early enough: tap (0, 0) — the only tap prefetched
+    // across the chunk boundary — reads pixels < R * (W + 2), i.e. pieces of slots 0..4 (issued at taps 0..4),
+    // and slot 8 holds pixels of halo rows >= R that no tap before (2, 0) touches.
+    // (Variants measured slower: two halo slots per tap so that the halo completes a tap early, 151 vs 142 us
+    // on 16384x640x5760 — a dead LDS-DMA slot still costs ~115 issue cycles; register-staged loaders —
+    // buffer_load into VGPRs two taps ahead, ds_write_b128 — 171 us, the loaders became the critical path.)
     int cur_c = c0, cur_t = 0;
     auto halo_dst = [&](int piece_slot, bool take) {
       const int pi = piece_slot * 4 + wave;
@@ -173,12 +174,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       __builtin_amdgcn_s_barrier();
       __amdgpu_buffer_rsrc_t rs;
       unsigned vo, so;
-      halo_src(cur_c + 1, cur_t <= 7, rs, vo, so);
+      halo_src(cur_c + 1, true, rs, vo, so);
       if constexpr (DO_LOAD)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + halo_dst(cur_t, cur_t <= 7)), 16, vo, so, 0, 0);
-      halo_src(cur_c + 1, cur_t == 7, rs, vo, so);
-      if constexpr (DO_LOAD)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + halo_dst(8, cur_t == 7)), 16, vo, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + halo_dst(cur_t, true)), 16, vo, so, 0, 0);
       const __amdgpu_buffer_rsrc_t rw =
           __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wk_gi < n_it ? recW : 0, 0x00020000);
       char* wdst = smem + (wk_gi & 3) * B_BYTES + wave * 1024;
