@@ -57,6 +57,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;
 
+// WT = image width (64, 32, 16): compile-time so that the fragments of one image row share ONE address register
+// (they are 16 pixels = 2048 B apart and 16 = 0 mod 8 keeps the swizzle term) and the MFMA waves compute
+// 64 / WT addresses per tap instead of four.
+template <int WT>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -77,9 +81,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
   const int c1 = min(nchunk, c0 + p.kps);
   const int n_it = (c1 - c0) * 9;
 
-  const int W = p.Wo, H = p.Ho, WH = W + 2;
-  const int R = BM / W;                             // output rows per tile
-  const int HP = (R + 2) * WH;                      // halo pixels
+  constexpr int W = WT, WH = WT + 2;
+  const int H = p.Ho;
+  constexpr int R = BM / W;                         // output rows per tile
+  constexpr int HP = (R + 2) * WH;                  // halo pixels
   const int tpi = (H * W) / BM;                     // tiles per image
   const int b = mt / tpi;
   const int y0 = (mt - b * tpi) * R;
@@ -204,31 +209,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
   const int fq = lane >> 4;
-  int p0[4];                                        // halo pixel of tap (0, 0) for fragment i
+  constexpr int NL = 64 / W;                        // image rows (= address leaders) in a wave's 64 pixels
+  constexpr int FPL = 4 / NL;                       // fragments per leader
+  int p0[NL];                                       // halo pixel of tap (0, 0) for leader l
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = wm * 64 + i * 16 + (lane & 15);
+  for (int l = 0; l < NL; ++l) {
+    const int q = wm * 64 + l * FPL * 16 + (lane & 15);
     const int r = q / W;
-    p0[i] = r * WH + (q - r * W);
+    p0[l] = r * WH + (q - r * W);
   }
   const int swb = (wn * WN + (lane & 15));
   const int fb0 = (swb * 8 + (fq ^ ((swb >> 1) & 7))) * 16;         // weight fragment, K half 0
   const int fb1 = fb0 ^ 64;                                         // K half 1: chunk index ^ 4
   // (rows j*16 further down keep the swizzle term: (row + 16 j) >> 1 & 7 == (row >> 1) & 7)
-  auto a_addr = [&](int i, int dt) {                // byte offset inside a halo buffer, K half 0
-    const int px = p0[i] + dt;
+  auto a_addr = [&](int l, int dt) {                // byte offset inside a halo buffer, K half 0, leader l
+    const int px = p0[l] + dt;
     return px * 128 + ((fq ^ (px & 7)) << 4);
   };
 
   __builtin_amdgcn_s_barrier();                     // halo of the first chunk and weight tiles 0..2 landed
   __builtin_amdgcn_sched_barrier(0);
   h8 xa0[4], xa1[4], wb0[J], wb1[J];
-  int aoff[4];                                      // addresses of the CURRENT tap (half 0)
+  int aoff[NL];                                     // leader addresses of the CURRENT tap (half 0)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    aoff[i] = a_addr(i, 0);
-    xa0[i] = *reinterpret_cast<const h8*>(smem + W_RING + aoff[i]);
-  }
+  for (int l = 0; l < NL; ++l) aoff[l] = a_addr(l, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    xa0[i] = *reinterpret_cast<const h8*>(smem + W_RING + aoff[i / FPL] + (i % FPL) * 2048);
 #pragma unroll
   for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb0 + j * 2048);
   int cur_ky = 0, cur_kx = 0, hsel = 0;             // tap of this iteration, halo buffer of this chunk
@@ -252,15 +259,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     const int nsel = hsel ^ w9;
     const char* hbn = smem + W_RING + nsel * HALO_BYTES;
     const int ndt = nky * WH + nkx;
-    int naoff[4];
+    int naoff[NL];
 #pragma unroll
     for (int k = 0; k < 4 * J; ++k) {               // K half 0; the half-1 fragments stream in behind
       const int jj = k / 4, ii = k % 4;
       acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
       if (k == 0) wb1[0] = *reinterpret_cast<const h8*>(wcur1);
-      else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(hb + (aoff[k - 1] ^ 64));
+      else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(hb + (aoff[(k - 1) / FPL] ^ 64) + ((k - 1) % FPL) * 2048);
       else if (k < 4 + J) wb1[k - 4] = *reinterpret_cast<const h8*>(wcur1 + (k - 4) * 2048);
-      else if (k < 8 + J) naoff[k - 4 - J] = a_addr(k - 4 - J, ndt);
+      else if (k < 4 + J + NL) naoff[k - 4 - J] = a_addr(k - 4 - J, ndt);
       __builtin_amdgcn_sched_barrier(0);
     }
     DADD_STAMP(c2s);
@@ -269,12 +276,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       const int jj = k / 4, ii = k % 4;
       acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
       if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(wnext);
-      else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(hbn + naoff[k - 1]);
+      else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(hbn + naoff[(k - 1) / FPL] + ((k - 1) % FPL) * 2048);
       else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) aoff[i] = naoff[i];
+    for (int l = 0; l < NL; ++l) aoff[l] = naoff[l];
     cur_kx = nkx;
     cur_ky = nky;
     hsel = nsel;
@@ -297,7 +304,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
 }  // namespace
 
 int dadd_init_conv_halo() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<32>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
   return DADD_OK;
 }
@@ -317,7 +328,9 @@ int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "conv_halo: operand larger than the 2 GiB buffer window");
   dim3 grid(a.mtiles * a.ntiles, nsplit);
-  hipLaunchKernelGGL(conv3x3_halo_kernel, grid, dim3(512), SMEM_BYTES, s, a);
+  if (a.Wo == 64) hipLaunchKernelGGL(conv3x3_halo_kernel<64>, grid, dim3(512), SMEM_BYTES, s, a);
+  else if (a.Wo == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, grid, dim3(512), SMEM_BYTES, s, a);
+  else hipLaunchKernelGGL(conv3x3_halo_kernel<16>, grid, dim3(512), SMEM_BYTES, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
