@@ -22,6 +22,7 @@
 //     chunk boundaries (the pixels tap (0, 0) needs are in the halo pieces issued during taps 0..4).
 // Split-K slices are ranges of chunks (fp32 slabs + splitk_finish_kernel, as for the implicit GEMM).
 #include <cstdlib>
+#include <type_traits>
 
 #include "dadd_common.h"
 #include "igemm_args.h"
@@ -227,47 +228,58 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     return px * 128 + ((fq ^ (px & 7)) << 4);
   };
 
+  // Leader addresses of all nine taps (independent of the chunk): the tap loop is unrolled by nine, every
+  // address is a register and the MFMA waves — the critical path — run no address or tap arithmetic at all
+  // (measured on 16384x640x5760: 134 us with ~30 VALU/SALU per tap on these waves, 118 us with one address
+  // per image row, see DESIGN.md for this version).
+  constexpr bool PRE = NL <= 2;                     // W = 16 (36 addresses) would spill: computed per tap there
+  int aoff9[PRE ? 9 : 1][NL];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int l = 0; l < NL; ++l) aoff9[tp][l] = a_addr(l, (tp / 3) * WH + (tp % 3));
+  }
+  auto addr_of = [&](auto TP, int l) {
+    constexpr int T = decltype(TP)::value;
+    if constexpr (PRE) return aoff9[T][l];
+    else {                                          // opaque copy: keeps the compiler from hoisting all 36 again
+      int pz = p0[l];
+      asm volatile("" : "+v"(pz));
+      const int px = pz + (T / 3) * WH + (T % 3);
+      return px * 128 + ((fq ^ (px & 7)) << 4);
+    }
+  };
+
   __builtin_amdgcn_s_barrier();                     // halo of the first chunk and weight tiles 0..2 landed
   __builtin_amdgcn_sched_barrier(0);
   h8 xa0[4], xa1[4], wb0[J], wb1[J];
-  int aoff[NL];                                     // leader addresses of the CURRENT tap (half 0)
-#pragma unroll
-  for (int l = 0; l < NL; ++l) aoff[l] = a_addr(l, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    xa0[i] = *reinterpret_cast<const h8*>(smem + W_RING + aoff[i / FPL] + (i % FPL) * 2048);
+    xa0[i] = *reinterpret_cast<const h8*>(smem + W_RING + addr_of(std::integral_constant<int, 0>{}, i / FPL) + (i % FPL) * 2048);
 #pragma unroll
   for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb0 + j * 2048);
-  int cur_ky = 0, cur_kx = 0, hsel = 0;             // tap of this iteration, halo buffer of this chunk
   [[maybe_unused]] unsigned long long sc_bar = 0, sc_h0 = 0, sc_h1 = 0;
   DADD_STAMP(c_begin);
-  for (int gi = 0; gi < n_it; ++gi) {
+  int gi = 0;
+  const char* hb = smem + W_RING;                   // halo buffer of the current chunk
+  const char* hbo = smem + W_RING + HALO_BYTES;     // ... of the next chunk
+  auto tap = [&](auto TP) {
+    constexpr int T = decltype(TP)::value, NT = (T + 1) % 9;
     DADD_STAMP(c0s);
     __builtin_amdgcn_s_barrier();                   // one barrier per tap on both sides
     DADD_STAMP(c1s);
     __builtin_amdgcn_sched_barrier(0);
-    const char* hb = smem + W_RING + hsel * HALO_BYTES;
     const char* wcur1 = smem + (gi & 3) * B_BYTES + fb1;
     const char* wnext = smem + ((gi + 1) & 3) * B_BYTES + fb0;
-    // next tap (selects only: the loop body is one basic block)
-    const int kx1 = cur_kx + 1;
-    const int w3 = kx1 == 3 ? 1 : 0;
-    const int nkx = w3 ? 0 : kx1;
-    const int ky1 = cur_ky + w3;
-    const int w9 = ky1 == 3 ? 1 : 0;                // chunk boundary: tap (0, 0) of the other halo buffer
-    const int nky = w9 ? 0 : ky1;
-    const int nsel = hsel ^ w9;
-    const char* hbn = smem + W_RING + nsel * HALO_BYTES;
-    const int ndt = nky * WH + nkx;
-    int naoff[NL];
+    const char* hbn = T == 8 ? hbo : hb;            // tap (0, 0) of the next chunk reads the other buffer
 #pragma unroll
     for (int k = 0; k < 4 * J; ++k) {               // K half 0; the half-1 fragments stream in behind
       const int jj = k / 4, ii = k % 4;
       acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
       if (k == 0) wb1[0] = *reinterpret_cast<const h8*>(wcur1);
-      else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(hb + (aoff[(k - 1) / FPL] ^ 64) + ((k - 1) % FPL) * 2048);
+      else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(hb + (addr_of(std::integral_constant<int, T>{}, (k - 1) / FPL) ^ 64) + ((k - 1) % FPL) * 2048);
       else if (k < 4 + J) wb1[k - 4] = *reinterpret_cast<const h8*>(wcur1 + (k - 4) * 2048);
-      else if (k < 4 + J + NL) naoff[k - 4 - J] = a_addr(k - 4 - J, ndt);
       __builtin_amdgcn_sched_barrier(0);
     }
     DADD_STAMP(c2s);
@@ -276,20 +288,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       const int jj = k / 4, ii = k % 4;
       acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
       if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(wnext);
-      else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(hbn + naoff[(k - 1) / FPL] + ((k - 1) % FPL) * 2048);
+      else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(hbn + addr_of(std::integral_constant<int, NT>{}, (k - 1) / FPL) + ((k - 1) % FPL) * 2048);
       else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(wnext + (k - 4) * 2048);
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int l = 0; l < NL; ++l) aoff[l] = naoff[l];
-    cur_kx = nkx;
-    cur_ky = nky;
-    hsel = nsel;
+    ++gi;
     __builtin_amdgcn_sched_barrier(0);
     DADD_STAMP(c3s);
     DADD_ACC(sc_bar, c0s, c1s);
     DADD_ACC(sc_h0, c1s, c2s);
     DADD_ACC(sc_h1, c2s, c3s);
+  };
+  for (int c = c0; c < c1; ++c) {
+    tap(std::integral_constant<int, 0>{});
+    tap(std::integral_constant<int, 1>{});
+    tap(std::integral_constant<int, 2>{});
+    tap(std::integral_constant<int, 3>{});
+    tap(std::integral_constant<int, 4>{});
+    tap(std::integral_constant<int, 5>{});
+    tap(std::integral_constant<int, 6>{});
+    tap(std::integral_constant<int, 7>{});
+    tap(std::integral_constant<int, 8>{});
+    const char* sw = hb;
+    hb = hbo;
+    hbo = sw;
   }
 #if DADD_IGEMM_EXP == 3
   if (wave == 0 && lane == 0 && p.partial && blockIdx.y == 0) {
