@@ -104,85 +104,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       const int n = n0 + row;
       w_v[j] = (n < p.N) ? (unsigned)(((size_t)n * p.K + (lch ^ ((row >> 1) & 7)) * 8) * 2) : OOB;
     }
-    // Halo piece `s` (s = 0..8) of this wave covers pixels (s * 4 + wave) * 8 + [0, 8): this lane's pixel
-    // advances by 32 per piece, so its (row, column) in the halo is kept as a running pair (a runtime-
-    // indexed table of the nine offsets lands in scratch, and a scratch load's vmcnt wait drains the queue).
-    const int px0 = wave * 8 + lrow;
-    const int hy0 = px0 / WH, hx0 = px0 - hy0 * WH;
-    const int sdy = 32 / WH, sdx = 32 - sdy * WH;
-    const int hchunk = (lch ^ lrow) * 8;            // (pixel & 7) == lrow for every piece
-    int l_px = px0, l_hy = hy0, l_hx = hx0, l_slot = 0;
-    auto halo_src = [&](int c, bool take, __amdgpu_buffer_rsrc_t& rs, unsigned& vo, unsigned& so) {
+    // Halo piece `s` (s = 0..8) of this wave covers pixels (s * 4 + wave) * 8 + [0, 8): byte offsets of this
+    // lane's 16 B in both sources, precomputed once; the tap loop below is unrolled by nine so that the slot
+    // index is a constant (a runtime-indexed table would land in scratch) and the loader waves — which share
+    // their SIMD's VALU issue with an MFMA wave — run no vector arithmetic in the steady state.
+    unsigned hv1[9], hv2[9];
+#pragma unroll
+    for (int sl = 0; sl < 9; ++sl) {
+      const int px = (sl * 4 + wave) * 8 + lrow;
+      const int hy = px / WH, hx = px - hy * WH;
+      const int y = y0 - 1 + hy, x = hx - 1;
+      const bool ok = px < HP && y >= 0 && y < H && x >= 0 && x < W;
+      const int chunk = lch ^ (px & 7);
+      const int pix = (b * H + y) * W + x;
+      hv1[sl] = ok ? (unsigned)((pix * p.C1 + chunk * 8) * 2) : OOB;
+      hv2[sl] = ok ? (unsigned)((pix * p.C2 + chunk * 8) * 2) : OOB;
+    }
+    int wk_tap = 0, wk_c = c0 * BK, wk_gi = 0;      // cursor of the NEXT weight tile to fetch
+    // halo piece `SL` of chunk c -> buffer (c - c0) & 1; pieces past the halo go to the dump area
+    auto issue_halo = [&](int c, auto SLC) {
+      constexpr int SL = decltype(SLC)::value;
       const bool have = c < c1;
       const bool second = (c * BK) >= p.C1;
       const int cb = second ? c * BK - p.C1 : c * BK;
-      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? base2 : p.x), 0,
-                                             (have && take) ? (second ? rec2 : rec1) : 0, 0x00020000);
-      const int y = y0 - 1 + l_hy, x = l_hx - 1;
-      const bool ok = take && l_px < HP && y >= 0 && y < H && x >= 0 && x < W;
-      const int pix = (b * H + y) * W + x;
-      vo = ok ? (unsigned)((pix * (second ? p.C2 : p.C1) + hchunk) * 2) : OOB;
-      so = (unsigned)(cb * 2);
-      // next piece (selects only); `take == false` is a dead slot and leaves the cursor alone
-      const bool last = l_slot == 8;
-      const int nx = l_hx + sdx, carry = nx >= WH ? 1 : 0;
-      const int a_px = last ? px0 : l_px + 32, a_hx = last ? hx0 : nx - (carry ? WH : 0);
-      const int a_hy = last ? hy0 : l_hy + sdy + carry, a_slot = last ? 0 : l_slot + 1;
-      l_px = take ? a_px : l_px;
-      l_hx = take ? a_hx : l_hx;
-      l_hy = take ? a_hy : l_hy;
-      l_slot = take ? a_slot : l_slot;
-    };
-    int wk_tap = 0, wk_c = c0 * BK, wk_gi = 0;      // cursor of the NEXT weight tile to fetch
-
-    // ---- prologue by LDS-DMA (once per workgroup): the whole halo of the first chunk, weight tiles 0, 1, 2
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {
-      __amdgpu_buffer_rsrc_t rs;
-      unsigned vo, so;
-      halo_src(c0, true, rs, vo, so);
-      const bool live = (s * 4 + wave) < live_pieces;
-      const int dst = live ? W_RING + (s * 4 + wave) * 1024 : DUMP_OFF + wave * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + dst), 16, vo, so, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wk_gi < n_it ? recW : 0, 0x00020000);
-      char* dst = smem + (wk_gi & 3) * B_BYTES + wave * 1024;
-      const unsigned koff = (unsigned)((wk_tap * Cin + wk_c) * 2);
-#pragma unroll
-      for (int j = 0; j < NBJ; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + j * 4096), 16, w_v[j], koff, 0, 0);
-      ++wk_gi;
-      ++wk_tap;                                     // taps 0, 1, 2 of the first chunk
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");   // everything but weight tile 2
-    __builtin_amdgcn_s_barrier();
-
-    // ---- LDS-DMA stream.  Iteration g (after its barrier, when the ring slot of tile g - 1 is free) issues halo
-    // piece t(g) of chunk(g) + 1 and THEN weight tile g + 3: the counted wait "all but the NBJ youngest" at the
-    // top of the next iteration therefore covers every halo piece and weight tile g + 1.  The last piece of a
-    // halo lands one tap after its chunk started, which is early enough: tap (0, 0) — the only tap prefetched
-    // across the chunk boundary — reads pixels < R * (W + 2), i.e. pieces of slots 0..4 (issued at taps 0..4),
-    // and slot 8 holds pixels of halo rows >= R that no tap before (2, 0) touches.
-    // (Variants measured slower: two halo slots per tap so that the halo completes a tap early, 151 vs 142 us
-    // on 16384x640x5760 — a dead LDS-DMA slot still costs ~115 issue cycles; register-staged loaders —
-    // buffer_load into VGPRs two taps ahead, ds_write_b128 — 171 us, the loaders became the critical path.)
-    int cur_c = c0, cur_t = 0;
-    auto halo_dst = [&](int piece_slot, bool take) {
-      const int pi = piece_slot * 4 + wave;
-      const int lmask = (take && (cur_c + 1) < c1 && pi < live_pieces) ? -1 : 0;   // mask arithmetic, no branch
-      return ((W_RING + ((cur_c + 1 - c0) & 1) * HALO_BYTES + pi * 1024) & lmask) | ((DUMP_OFF + wave * 1024) & ~lmask);
-    };
-    for (int gi = 0; gi < n_it; ++gi) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");
-      __builtin_amdgcn_s_barrier();
-      __amdgpu_buffer_rsrc_t rs;
-      unsigned vo, so;
-      halo_src(cur_c + 1, true, rs, vo, so);
+      const bool live = have && (SL * 4 + wave) < live_pieces;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(second ? base2 : p.x), 0, have ? (second ? rec2 : rec1) : 0, 0x00020000);
+      const int lmask = live ? -1 : 0;              // mask arithmetic, no branch
+      const int dst = ((W_RING + ((c - c0) & 1) * HALO_BYTES + (SL * 4 + wave) * 1024) & lmask) |
+                      ((DUMP_OFF + wave * 1024) & ~lmask);
       if constexpr (DO_LOAD)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + halo_dst(cur_t, true)), 16, vo, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + dst), 16, second ? hv2[SL] : hv1[SL],
+                                                 (unsigned)(cb * 2), 0, 0);
+    };
+    auto issue_w = [&]() {                          // weight tile wk_gi -> ring slot wk_gi & 3 (dead past the end)
       const __amdgpu_buffer_rsrc_t rw =
           __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, wk_gi < n_it ? recW : 0, 0x00020000);
       char* wdst = smem + (wk_gi & 3) * B_BYTES + wave * 1024;
@@ -195,9 +150,49 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
       const int w1 = wk_tap + 1, ww = w1 == 9 ? 1 : 0;
       wk_tap = ww ? 0 : w1;
       wk_c += ww ? BK : 0;
-      const int t1 = cur_t + 1, wrap = t1 == 9 ? 1 : 0;
-      cur_t = wrap ? 0 : t1;
-      cur_c += wrap;
+    };
+
+    // ---- prologue: the whole halo of the first chunk, weight tiles 0, 1, 2
+    issue_halo(c0, std::integral_constant<int, 0>{});
+    issue_halo(c0, std::integral_constant<int, 1>{});
+    issue_halo(c0, std::integral_constant<int, 2>{});
+    issue_halo(c0, std::integral_constant<int, 3>{});
+    issue_halo(c0, std::integral_constant<int, 4>{});
+    issue_halo(c0, std::integral_constant<int, 5>{});
+    issue_halo(c0, std::integral_constant<int, 6>{});
+    issue_halo(c0, std::integral_constant<int, 7>{});
+    issue_halo(c0, std::integral_constant<int, 8>{});
+    issue_w();
+    issue_w();
+    issue_w();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");   // everything but weight tile 2
+    __builtin_amdgcn_s_barrier();
+
+    // ---- LDS-DMA stream.  Iteration g (after its barrier, when the ring slot of tile g - 1 is free) issues halo
+    // piece t(g) of chunk(g) + 1 and THEN weight tile g + 3: the counted wait "all but the NBJ youngest" at the
+    // top of the next iteration therefore covers every halo piece and weight tile g + 1.  The last piece of a
+    // halo lands one tap after its chunk started, which is early enough: tap (0, 0) — the only tap prefetched
+    // across the chunk boundary — reads pixels < R * (W + 2), i.e. pieces of slots 0..4 (issued at taps 0..4),
+    // and slot 8 holds pixels of halo rows >= R that no tap before (2, 0) touches.
+    // (Variants measured slower: two halo slots per tap so that the halo completes a tap early, 151 vs 142 us
+    // on 16384x640x5760 — a dead LDS-DMA slot still costs ~115 issue cycles; register-staged loaders —
+    // buffer_load into VGPRs two taps ahead, ds_write_b128 — 171 us, the loaders became the critical path.)
+    auto ltap = [&](int c, auto SLC) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_halo(c + 1, SLC);
+      issue_w();
+    };
+    for (int c = c0; c < c1; ++c) {
+      ltap(c, std::integral_constant<int, 0>{});
+      ltap(c, std::integral_constant<int, 1>{});
+      ltap(c, std::integral_constant<int, 2>{});
+      ltap(c, std::integral_constant<int, 3>{});
+      ltap(c, std::integral_constant<int, 4>{});
+      ltap(c, std::integral_constant<int, 5>{});
+      ltap(c, std::integral_constant<int, 6>{});
+      ltap(c, std::integral_constant<int, 7>{});
+      ltap(c, std::integral_constant<int, 8>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
