@@ -154,10 +154,11 @@ int dadd_graph_launch(void* graph_exec, void* stream);
 int dadd_graph_destroy(void* graph_exec);
 
 /* ---- in-library HIP-event timing of one kernel family (bench.py roofline) -------------------
- * kind 1 = every implicit GEMM, kind 2 = only conv3x3_halo_kernel (the dominant kernel of
- * the UNet step).  While enabled (eager launches only, never during capture) every
- * launch of that family is bracketed by events on its own stream.  dadd_prof_end fills
- * out[0]=launches, out[1]=total ms, out[2]=total algorithmic flop (2*M*N*K). */
+ * kind 1 = every implicit GEMM / conv, kind 2 = only igemm_dma_kernel<160,false,false,true> (the kernel
+ * with the largest share of GPU time in the UNet step), kind 3 = only conv3x3_halo_kernel<64>.  While
+ * enabled (eager launches only, never during capture) every launch of that family is bracketed by events
+ * on its own stream.  dadd_prof_end fills out[0]=launches, out[1]=total ms, out[2]=total algorithmic
+ * flop (2*M*N*K). */
 int dadd_prof_begin(int kind);
 int dadd_prof_end(double out[3]);
 /* median interval (ms) of an empty event pair on `stream`: subtracted per launch by bench.py */

@@ -108,7 +108,7 @@ int dadd_graph_destroy(void* graph_exec) {
 }
 
 int dadd_prof_begin(int kind) {
-  DADD_REQUIRE(kind == 1 || kind == 2, "prof_begin: unknown kernel family %d", kind);
+  DADD_REQUIRE(kind >= 1 && kind <= 3, "prof_begin: unknown kernel family %d", kind);
   g_prof.kind = kind;
   g_prof.used = 0;
   g_prof.flop.clear();

@@ -356,9 +356,12 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     a.splitk = halo_ns;
     DADD_REQUIRE(halo_ns == 1 || a.partial != nullptr, "igemm: split-K needs a partial buffer");
   }
-  // profiling family 1 = every implicit GEMM / conv; family 2 = exactly conv3x3_halo_kernel, the dominant
-  // kernel of the UNet step (one row of a rocprofv3 --stats summary)
-  const bool prof = dadd_prof_active(1) || (dadd_prof_active(2) && halo);
+  // profiling family 1 = every implicit GEMM / conv; family 2 = exactly igemm_dma_kernel<160, false, false, true>
+  // (the kernel with the largest share of GPU time: one row of a rocprofv3 --stats summary); family 3 = exactly
+  // conv3x3_halo_kernel<64>
+  const bool prof = dadd_prof_active(1) ||
+                    (dadd_prof_active(2) && !halo && dma && tile_n == 160 && !a.ups && !dadd_igemm_dma_persistent(a, nsplit)) ||
+                    (dadd_prof_active(3) && halo && a.Wo == 64);
   if (prof) dadd_prof_pre(s);
   if (halo)
     rc = dadd_launch_conv_halo(a, halo_ns, s);

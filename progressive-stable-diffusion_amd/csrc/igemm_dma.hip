@@ -232,11 +232,29 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
       }
     }
   };
+  // Loader waves share their SIMD's VALU issue with an MFMA wave (conv_halo.hip: every vector instruction of
+  // the loaders shows up as lost MFMA issue), so the per-piece "tap inside the image? which source?" selects
+  // are cached and recomputed only when the tap or the source changes — never for a plain linear layer.
+  unsigned a_eff[NA];
+  int eff_key = -1;
   auto issue = [&]() {   // whole tile at once (prologue; loader waves)
     const IssueCtx c = issue_begin();
     if constexpr (EXP != 2) {
+      if constexpr (!UPS) {
+        const int key = c.tap * 2 + (c.second ? 1 : 0) + (PERS ? iss_tile * 32 : 0);
+        if (key != eff_key) {                       // wave-uniform
+          eff_key = key;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) issue_a(c, i);
+          for (int i = 0; i < NA; ++i)
+            a_eff[i] = ((a_mask[i] >> c.tap) & 1u) ? (c.second ? a_v2[i] : a_v1[i]) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, a_eff[i], c.soff, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) issue_a(c, i);
+      }
 #pragma unroll
       for (int jj = 0; jj < NBJ; ++jj) issue_w(c, jj);
     }

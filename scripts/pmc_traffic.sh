@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = kname(r["Kernel_Name"])
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     res[c] = {k: {"sum_kb": v[0], "dispatches": v[1], "avg_kb": v[0] / v[1]} for k, v in agg.items()}
-dom = [k for k in res["FETCH_SIZE"] if "conv3x3_halo_kernel" in k]
+dom = [k for k in res["FETCH_SIZE"] if "igemm_dma_kernel<160, false, false, true>" in k]
 summary = {"counters": res}
 if dom:
     k = dom[0]
