@@ -71,7 +71,8 @@ def geglu_interleave(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, to
     return w[src].contiguous(), b[src].contiguous()
 
 
-def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> Tuple[int, int, int]:
+def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False,
+                  residual: bool = True) -> Tuple[int, int, int]:
     """(tile_m, splitk, tune_flags) for one implicit GEMM, from measurements over every layer shape
     of the B=4 / 512x512 step on MI355X (scripts/op_bench.py, profiles/r01_*_op_bench.txt):
       * K >= 12 tiles: the wave-specialised LDS-DMA ring kernel, 128-row tiles, ONE workgroup per CU;
@@ -80,8 +81,9 @@ def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> T
         with >= 8 tiles per CU (VAE) the ring is kept running over a run of tiles (DADD_TUNE_PERSIST);
       * short K with more 128-row tiles than CUs (qkv, the GEGLU projection at 32x32): the same kernel
         with its ring kept running over a run of output tiles per workgroup (DADD_TUNE_PERSIST);
-      * other short-K linears: the register-staged kernel, two workgroups per CU, 64-row tiles when
-        128-row tiles would not give ~512 workgroups;
+      * other short-K linears: without a residual input the LDS-DMA kernel (its loaders run no vector
+        arithmetic), with one the register-staged kernel, two workgroups per CU, 64-row tiles when 128-row
+        tiles would not give ~512 workgroups;
       * GEGLU at 64x64 (2560 tiles, erf epilogue as long as the MFMAs): register-staged 64-row tiles."""
     nkt = k // 64
     nt = math.ceil(n / tile_n)
@@ -95,9 +97,13 @@ def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False) -> T
             return 128, 1, L.TUNE_NODMA
         per = 16 if t128 > 64 else (10 if t128 > 16 else 8)
         sk = max(1, min(round(N_CU / t128), nkt // per, 32))
+        if not residual and nkt <= 20:      # plain projections: one pass beats slabs + finish (15.0 vs 18.9 us)
+            sk = 1
         return 128, sk, (L.TUNE_PERSIST if sk == 1 and t128 >= 8 * N_CU else 0)   # VAE: >= 8 tiles per CU
     if t128 > N_CU:
         return 128, 1, L.TUNE_PERSIST
+    if not residual and nkt >= 5:           # q / proj_in style linears without a residual read: DMA ring wins
+        return 128, 1, 0
     return (128 if t128 >= 2 * N_CU else 64), 1, L.TUNE_NODMA
 
 
@@ -160,7 +166,7 @@ class _Plan:
         n = w.shape[0]
         tile_n = 128 if (flags & L.EPI_GEGLU) or n % 160 else 160
         m = out_shape[0] * out_shape[1] * out_shape[2]
-        tile_m, sk, tune = choose_tiling(m, n, w.shape[1], tile_n, bool(flags & L.EPI_GEGLU))
+        tile_m, sk, tune = choose_tiling(m, n, w.shape[1], tile_n, bool(flags & L.EPI_GEGLU), residual is not None)
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | tune

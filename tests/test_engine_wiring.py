@@ -64,6 +64,8 @@ def test_splitk_heuristic():
     assert E.choose_tiling(1024, 1280, 11520, 160) == (128, 4, 0)
     assert E.choose_tiling(256, 1280, 11520, 160) == (128, 16, 0)           # 8x8 level: 16 tiles x 16 splits
     assert E.choose_tiling(1024, 1280, 1280, 160) == (128, 2, 0)
+    assert E.choose_tiling(1024, 1280, 1280, 160, residual=False) == (128, 1, 0)
+    assert E.choose_tiling(16384, 320, 320, 160, residual=False) == (128, 1, 0)   # q projection: DMA ring
     assert E.choose_tiling(1048576, 128, 1152, 128) == (128, 1, L.TUNE_NODMA)      # VAE 512x512, 128 channels
     assert E.choose_tiling(262144, 256, 2304, 128) == (128, 1, L.TUNE_PERSIST)    # VAE 256x256: 16 tiles per CU
     assert E.choose_splitk(64, 1280, 768, 160) == 1
