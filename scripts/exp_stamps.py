@@ -32,5 +32,3 @@ for b, side, cin, cout in ((4, 64, 640, 640), (4, 64, 320, 320), (4, 32, 640, 64
     print(f"conv {b}x{side}x{side} {cin}->{cout}: {nit} taps x chunks per workgroup, stamps in s_memtime ticks (shader-clock cycles)")
     print(f"  MFMA wave : loop {m[3]:9.0f} = barrier {m[0]:9.0f} ({100 * m[0] / m[3]:4.1f} %) + K half 0 {m[1]:9.0f} "
           f"({100 * m[1] / m[3]:4.1f} %) + K half 1 {m[2]:9.0f} ({100 * m[2] / m[3]:4.1f} %);  per tap {m[3] / nit:.0f} cycles (MFMA alone: 640)")
-    print(f"  loader    : loop {m[7]:9.0f} = vmcnt wait {m[4]:9.0f} ({100 * m[4] / m[7]:4.1f} %) + barrier {m[5]:9.0f} "
-          f"({100 * m[5] / m[7]:4.1f} %) + issue {m[6]:9.0f} ({100 * m[6] / m[7]:4.1f} %)")
