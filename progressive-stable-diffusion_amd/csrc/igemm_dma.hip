@@ -240,21 +240,23 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
   auto issue = [&]() {   // whole tile at once (prologue; loader waves)
     const IssueCtx c = issue_begin();
     if constexpr (EXP != 2) {
-      if constexpr (!UPS) {
-        const int key = c.tap * 2 + (c.second ? 1 : 0) + (PERS ? iss_tile * 32 : 0);
-        if (key != eff_key) {                       // wave-uniform
-          eff_key = key;
+      const int key = c.tap * 2 + (c.second ? 1 : 0) + (PERS ? iss_tile * 32 : 0);
+      if (key != eff_key) {                         // wave-uniform
+        eff_key = key;
 #pragma unroll
-          for (int i = 0; i < NA; ++i)
+        for (int i = 0; i < NA; ++i) {
+          if constexpr (!UPS) {
             a_eff[i] = ((a_mask[i] >> c.tap) & 1u) ? (c.second ? a_v2[i] : a_v1[i]) : OOB;
+          } else {   // nearest-2x upsample: the source pixel is (iy>>1, ix>>1) of the virtual image
+            const int iy = a_y[i] + c.ky, ix = a_x[i] + c.kx;
+            const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
+            a_eff[i] = ok ? (unsigned)(((a_pix[i] + (iy >> 1) * p.Wi + (ix >> 1)) * c.cs + a_cc[i]) * 2) : OOB;
+          }
         }
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, a_eff[i], c.soff, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) issue_a(c, i);
       }
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, a_eff[i], c.soff, 0, 0);
 #pragma unroll
       for (int jj = 0; jj < NBJ; ++jj) issue_w(c, jj);
     }
