@@ -391,7 +391,8 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   p.RP = 256 / p.TV;
   // stat chunks: at least two passes of rows per block, at most 128 per sample
   int nchunk = HW / (2 * p.RP > 16 ? 2 * p.RP : 16);
-  if (nchunk > 128) nchunk = 128;
+  static const int chunk_max = getenv("DADD_GN_CHUNK_MAX") ? atoi(getenv("DADD_GN_CHUNK_MAX")) : 128;   // A/B only
+  if (nchunk > chunk_max) nchunk = chunk_max;
   if (nchunk < 1) nchunk = 1;
   if (nchunk > DADD_GN_MAX_CHUNKS - 1) nchunk = DADD_GN_MAX_CHUNKS - 1;
   p.stats = ws + (size_t)B * (DADD_GN_MAX_CHUNKS - 1) * groups * 2;   // last chunk slot of the workspace
