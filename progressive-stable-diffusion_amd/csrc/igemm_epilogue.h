@@ -61,21 +61,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
       }
     }
   }
-  // residual tile first, all loads in flight at once: issued one by one inside the store loop each load's
-  // latency was exposed (N=C linears with a residual: 16.6 us against 10.4 us without)
-  h4 rres[J][MI];
-  if ((p.flags & DADD_EPI_RESIDUAL) && !(p.flags & DADD_EPI_GEGLU)) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm * WM + i * 16 + mc;
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        const int n = n0 + wn * WN + j * 16 + g * 4;
-        rres[j][i] = (m < p.M && n < p.N) ? *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n)
-                                          : h4{0, 0, 0, 0};
-      }
-    }
-  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * WM + i * 16 + mc;
@@ -111,7 +96,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
       if (p.flags & DADD_EPI_ROWVEC)
         v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);
       if (p.flags & DADD_EPI_RESIDUAL) {
-        const h4 rv = rres[j][i];
+        const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
       }
