@@ -194,8 +194,20 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
     const int m = (int)(idx / n4);
     const int n = (int)(idx - (size_t)m * n4) * 4;
     f4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsplit; ++s)
-      v += *reinterpret_cast<const f4*>(p.partial + ((size_t)s * p.M + m) * p.N + n);
+    const float* slab = p.partial + (size_t)m * p.N + n;
+    const size_t sstride = (size_t)p.M * p.N;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {     // four slabs in flight, summed in slice order (bit-reproducible)
+      const f4 t0 = *reinterpret_cast<const f4*>(slab + (size_t)s * sstride);
+      const f4 t1 = *reinterpret_cast<const f4*>(slab + (size_t)(s + 1) * sstride);
+      const f4 t2 = *reinterpret_cast<const f4*>(slab + (size_t)(s + 2) * sstride);
+      const f4 t3 = *reinterpret_cast<const f4*>(slab + (size_t)(s + 3) * sstride);
+      v += t0;
+      v += t1;
+      v += t2;
+      v += t3;
+    }
+    for (; s < nsplit; ++s) v += *reinterpret_cast<const f4*>(slab + (size_t)s * sstride);
     if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
     if (p.flags & DADD_EPI_ROWVEC)
       v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)(m / HoWo) * p.ld_rowvec + n);
