@@ -301,71 +301,58 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs p) {
 
 constexpr int GN_FUSED_MAX_BYTES = 16 * 1024;   // measured: wins only below ~16 KiB per (batch, group) slab
 
-// LayerNorm: R rows per wave, the rows live in registers (exact two-pass variance); all R row loads are issued
-// before the first reduction (one row per wave left a single 640-B load in flight per wave: 2.7 TB/s).
+// LayerNorm: one wave per row, the row lives in registers (exact two-pass variance).
 constexpr int LN_MAXV = 4;  // C <= 8*64*4 = 2048
-template <int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         half_t* __restrict__ out, int M, int C,
                                                         float eps) {
   const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-  if (row0 >= M) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
   const int nvec = C >> 3;
-  h8 v[R][LN_MAXV];
+  const half_t* xr = x + (size_t)row * C;
+  h8 v[LN_MAXV];
+  float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = row0 + r < M ? row0 + r : M - 1;        // tail rows re-read the last row (not stored)
-    const half_t* xr = x + (size_t)row * C;
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+      v[u] = *reinterpret_cast<const h8*>(xr + i * 8);
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
-      const int i = lane + 64 * u;
-      if (i < nvec) v[r][u] = *reinterpret_cast<const h8*>(xr + i * 8);
+      for (int e = 0; e < 8; ++e) sum += (float)v[u][e];
     }
   }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (row0 + r >= M) break;
-    float sum = 0.f;
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
-      if (lane + 64 * u < nvec) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += (float)v[r][u][e];
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[u][e] - mean;
+        sq += d * d;
       }
     }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
-      if (lane + 64 * u < nvec) {
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+      h8 o;
+      const f4 g0 = *reinterpret_cast<const f4*>(gamma + i * 8);
+      const f4 g1 = *reinterpret_cast<const f4*>(gamma + i * 8 + 4);
+      const f4 b0 = *reinterpret_cast<const f4*>(beta + i * 8);
+      const f4 b1 = *reinterpret_cast<const f4*>(beta + i * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = (float)v[r][u][e] - mean;
-          sq += d * d;
-        }
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)(((float)v[u][e] - mean) * rstd * g0[e] + b0[e]);
+        o[e + 4] = (half_t)(((float)v[u][e + 4] - mean) * rstd * g1[e] + b1[e]);
       }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-    half_t* orow = out + (size_t)(row0 + r) * C;
-#pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
-      const int i = lane + 64 * u;
-      if (i < nvec) {
-        h8 o;
-        const f4 g0 = *reinterpret_cast<const f4*>(gamma + i * 8);
-        const f4 g1 = *reinterpret_cast<const f4*>(gamma + i * 8 + 4);
-        const f4 b0 = *reinterpret_cast<const f4*>(beta + i * 8);
-        const f4 b1 = *reinterpret_cast<const f4*>(beta + i * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (half_t)(((float)v[r][u][e] - mean) * rstd * g0[e] + b0[e]);
-          o[e + 4] = (half_t)(((float)v[r][u][e + 4] - mean) * rstd * g1[e] + b1[e]);
-        }
-        *reinterpret_cast<h8*>(orow + i * 8) = o;
-      }
+      *reinterpret_cast<h8*>(out + (size_t)row * C + i * 8) = o;
     }
   }
 }
@@ -444,12 +431,9 @@ extern "C" int dadd_layernorm_f16(const void* x, const float* gamma, const float
                "layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXV);
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(out) && dadd_aligned16(gamma) &&
                    dadd_aligned16(beta), "layernorm: pointers must be 16-byte aligned");
-  if (M >= 8192 && C <= 8 * 64 * 2)     // big maps: four rows per wave (registers: 4 rows x 2 vectors)
-    hipLaunchKernelGGL(layernorm_kernel<4>, dim3((M + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const half_t*>(x), gamma, beta, static_cast<half_t*>(out), M, C, eps);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const half_t*>(x), gamma, beta, static_cast<half_t*>(out), M, C, eps);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), gamma, beta,
+                     static_cast<half_t*>(out), M, C, eps);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

@@ -245,7 +245,7 @@ def test_groupnorm(hip, c1, c2, hw, silu, eps):
     close(o, o_ref, 3e-3, 2e-3, f"groupnorm c{c1}+{c2} hw{hw}")
 
 
-@pytest.mark.parametrize("m,c", [(100, 320), (37, 640), (64, 1280), (8195, 320), (16384, 640), (8192, 1280)])  # >= 8192 rows: 4 rows per wave
+@pytest.mark.parametrize("m,c", [(100, 320), (37, 640), (64, 1280)])
 def test_layernorm(hip, m, c):
     x = rnd((m, c), 26, 2.0) + 0.5
     gamma, beta = rnd((c,), 27, 0.2, F32) + 1.0, rnd((c,), 28, 0.2, F32)
