@@ -129,6 +129,16 @@ int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, i
 int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* gates, float lambda,
                        int mode, int B, int N, int heads, int d, int T, int ld_kv, void* stream);
 
+/* The whole attn2 block of the routing-gates processor as one launch.  x: LayerNorm output [B*HW][C];
+ * mcat [B][384][C]: row (h*3+p)*16+t = log2(e)/sqrt(d) * K_p[b,t,h,:] . W_q[h*d:(h+1)*d, :]   (h < 8 heads,
+ * p = 0 anatomy (tokens 16..31, to_k), 1 disease (tokens 0..15, to_k_dis), 2 delta (tokens 32..47, to_k_dis));
+ * vw [B][C][384]: column (h*3+p)*16+t = gate_p * W_o[:, h*d:(h+1)*d] . V_p[b,t,h,:]  (gate_2 = lambda);
+ * out = softmax16(x mcat^T) vw^T + bias + residual, 24 independent 16-wide softmaxes per token.
+ * H*W % 128 == 0, C % 320 == 0.  Replaces to_q + SplitInjectionAttentionProcessor.__call__:142-181 + to_out
+ * (src/models/attention_processor_routing_gates.py:118-190) — exact algebra, other rounding points. */
+int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const float* bias,
+                         const void* residual, void* out, int B, int HW, int C, void* stream);
+
 /* ---- sampler glue --------------------------------------------------------------------------
  * Sinusoidal timestep features (flip_sin_to_cos, shift 0): out[m][0:dim/2]=cos, [dim/2:]=sin. */
 int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream);

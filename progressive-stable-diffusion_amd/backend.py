@@ -148,6 +148,13 @@ class HipBackend:
                                             b, n, heads, c // heads, kv.shape[1], kv.stride(1),
                                             self.s))
 
+    def attn2_fused(self, x, mcat, vw, bias, residual, out):
+        """x, residual, out [B,HW,C]; mcat [B,384,C]; vw [B,C,384] (include/dadd_hip.h)."""
+        b, hw, c = x.shape
+        assert mcat.shape == (b, 384, c) and vw.shape == (b, c, 384) and out.shape == x.shape
+        L.check(self.lib.dadd_attn2_fused_f16(_p(x), _p(mcat), _p(vw), _p(bias), _p(residual), _p(out),
+                                              b, hw, c, self.s))
+
     def timestep_features(self, t, out):
         assert t.dtype == torch.int64 and out.dtype == torch.float32
         L.check(self.lib.dadd_timestep_features_f32(_p(t), _p(out), out.shape[0], out.shape[1], self.s))

@@ -21,6 +21,7 @@ computed once per sampling run.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -230,6 +231,19 @@ class UNetPlan(_Plan):
                              for _ in range(2)]                     # [cond, uncond]
         self.cond16 = be.zeros((batch, 1, self.T, 768), F16)
         self.kv_slot = 0
+        # ---- attn2 folded into ONE kernel per block (dadd_attn2_fused_f16): with 16 keys per pathway
+        # q K^T = x (W_q K^T) and P V W_o^T = P (V W_o^T), so the step-invariant conditioning absorbs both
+        # projections.  Sites whose map is smaller than one 128-token tile (8x8) keep the three-kernel path.
+        self.fused_attn2 = bool(use_routing_gates) and os.environ.get("DADD_NO_FUSED_ATTN2") is None
+        self.a2, self._a2_dirty, self._a2_lam = {}, True, None
+        if self.fused_attn2:
+            for site, c in self.sites:
+                hw = self._site_hw(site)
+                if hw % 128 == 0 and c % 320 == 0:
+                    ap = f"{u}{site}.transformer_blocks.0.attn2"
+                    self.a2[site] = dict(
+                        wq=self.dev(sd[ap + ".to_q.weight"].float()), wo=self.dev(sd[ap + ".to_out.0.weight"].float()),
+                        mcat=be.zeros((batch, 384, c), F16), vw=be.zeros((batch, c, 384), F16))
         # ---- I/O
         self.lat_in = be.zeros((batch, 4, side, side), F32)
         self.eps_out = [be.zeros((batch, 4, side, side), F32) for _ in range(2)]
@@ -242,6 +256,16 @@ class UNetPlan(_Plan):
         n += ["mid_block.resnets.0", "mid_block.resnets.1"]
         n += [f"up_blocks.{i}.resnets.{j}" for i in range(4) for j in range(3)]
         return n
+
+    def _site_hw(self, site: str) -> int:
+        """Tokens per sample at an attention site (latent side S: 64x64 -> S^2, S^2/4, S^2/16, mid S^2/64)."""
+        if site.startswith("down_blocks."):
+            r = self.S >> int(site.split(".")[1])
+        elif site.startswith("up_blocks."):
+            r = self.S >> (3 - int(site.split(".")[1]))
+        else:
+            r = self.S >> 3
+        return r * r
 
     @staticmethod
     def _attn_sites():
@@ -302,11 +326,17 @@ class UNetPlan(_Plan):
         self.pool.put(hs)
         # attn2 (DADD cross-attention)
         self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
-        q = self.conv(ln, self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
-        self.rec(self._xattn, site, q.view(b, h * w_, c), att.view(b, h * w_, c))
-        self.pool.put(q)
-        h3 = self.conv(att, self.w(tb + ".attn2.to_out.0.weight"), shp,
-                       bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0)
+        if site in self.a2:          # one kernel: x (W_q K^T) -> 24 softmaxes -> P (V W_o^T) + bias + residual
+            st = self.a2[site]
+            h3 = self.pool.get(shp)
+            self.rec(self.be.attn2_fused, ln.view(b, h * w_, c), st["mcat"], st["vw"],
+                     self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c))
+        else:
+            q = self.conv(ln, self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
+            self.rec(self._xattn, site, q.view(b, h * w_, c), att.view(b, h * w_, c))
+            self.pool.put(q)
+            h3 = self.conv(att, self.w(tb + ".attn2.to_out.0.weight"), shp,
+                           bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0)
         self.pool.put(h2, att)
         # GEGLU feed-forward
         self.rec(self.be.layernorm, h3, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"), ln)
@@ -394,6 +424,35 @@ class UNetPlan(_Plan):
         self.be.copy_(self.cond16, cond)
         for site, _ in self.sites:
             self.be.igemm(self.cond16, self.kv_w[site], self.kv[site][slot], taps=1, pad=0)
+        if slot == 0:
+            self._a2_dirty = True
+
+    def prepare_attn2(self, lam: float):
+        """Fold W_q / W_o and the gates into the conditioning of the fused attn2 sites (once per run;
+        never inside a graph capture: a no-op when neither the conditioning nor lambda changed)."""
+        if not self.a2 or (not self._a2_dirty and self._a2_lam == float(lam)):
+            return
+        B = self.B
+        with self.be.ctx(), torch.no_grad():
+            for site, c in self.sites:
+                st = self.a2.get(site)
+                if st is None:
+                    continue
+                d = c // HEADS
+                kv = self.kv[site][0].view(B, self.T, 4 * c).float()
+                hd = lambda t: t.reshape(B, 16, HEADS, d)                     # noqa: E731
+                ks = [hd(kv[:, 16:32, 0:c]), hd(kv[:, 0:16, 2 * c:3 * c]), hd(kv[:, 32:48, 2 * c:3 * c])]
+                vs = [hd(kv[:, 16:32, c:2 * c]), hd(kv[:, 0:16, 3 * c:4 * c]), hd(kv[:, 32:48, 3 * c:4 * c])]
+                g = self.gates[site]
+                gp = [g[0], g[1], torch.tensor(float(lam), device=g.device)]
+                wq = st["wq"].view(HEADS, d, c)
+                wo = st["wo"].view(c, HEADS, d)
+                scale = math.log2(math.e) / math.sqrt(d)
+                m = torch.stack([torch.einsum("bthd,hdc->bhtc", k, wq) for k in ks], dim=2) * scale   # b h p t c
+                v = torch.stack([torch.einsum("nhd,bthd->bnht", wo, x) * gg for x, gg in zip(vs, gp)], dim=3)  # b n h p t
+                st["mcat"].copy_(m.reshape(B, 384, c))
+                st["vw"].copy_(v.reshape(B, c, 384))
+        self._a2_dirty, self._a2_lam = False, float(lam)
 
     def time_rows(self, t: torch.Tensor, out: torch.Tensor):
         """rows[m] = cat_r time_emb_proj_r(SiLU(MLP(sinusoid(t[m]))))  for a vector of timesteps."""
@@ -428,6 +487,7 @@ class UNetPlan(_Plan):
             self.set_cond(cond, 0)
         self.time_rows(self.be.to_device(t.contiguous()), self.temb_rows)
         self.be.copy_(self.lat_in, latents.float())
+        self.prepare_attn2(lam)
         self.run_slot(0, lam)
         return self.be.clone(self.eps_out[0])
 
@@ -565,6 +625,7 @@ class DdimLoop:
 
     def _one_step(self, lam: float, do_cfg: bool, guidance: float):
         u = self.u
+        u.prepare_attn2(lam)          # a no-op unless the conditioning or lambda changed since the last call
         self.be.begin_step(self.table, u.temb_rows, self.coef, self.cur_coef, self.step)
         u.run_slot(0, lam)
         if do_cfg:
@@ -576,6 +637,7 @@ class DdimLoop:
             trace: Optional[list] = None):
         """Runs all prepared steps in place on ``unet.lat_in``."""
         self.be.zero_(self.step)
+        self.u.prepare_attn2(lam)
         if trace is not None or not use_graph:
             for _ in range(self.nsteps):
                 self._one_step(lam, do_cfg, guidance)

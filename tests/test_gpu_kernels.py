@@ -287,6 +287,25 @@ def test_tri_xattn(hip, d, mode, lam):
     close(o, o_ref, 4e-3, 4e-3, f"tri_xattn d{d} mode{mode} lam{lam}")
 
 
+@pytest.mark.parametrize("b,hw,c", [(2, 256, 320), (1, 1024, 640), (2, 128, 1280)])
+def test_attn2_fused(hip, b, hw, c):
+    """x (W_q K^T) -> 24 independent 16-wide softmaxes -> P (V W_o^T) + bias + residual in one launch, against the
+    same arithmetic in torch (P rounded to fp16 in both)."""
+    x, res = rnd((b, hw, c), 90), rnd((b, hw, c), 91)
+    mcat = rnd((b, 384, c), 92, 2.0 / math.sqrt(c))          # scores of a few units (log2 domain)
+    vw = rnd((b, c, 384), 93, 0.5)
+    bias = rnd((c,), 94, 0.1, F32)
+    o_ref = torch.zeros(b, hw, c, dtype=F16)
+    REF.attn2_fused(x, mcat, vw, bias, res, o_ref)
+    o = hip.zeros((b, hw, c), F16)
+    hip.attn2_fused(dev(hip, x), dev(hip, mcat), dev(hip, vw), dev(hip, bias), dev(hip, res), o)
+    hip.synchronize()
+    close(o, o_ref, 4e-3, 3e-3, f"attn2_fused {b}x{hw}x{c}")
+    with pytest.raises(ValueError):
+        hip.attn2_fused(dev(hip, x[:, :64]), dev(hip, mcat), dev(hip, vw), None, dev(hip, res[:, :64]),
+                        hip.zeros((b, 64, c), F16))          # fewer than 128 tokens per sample
+
+
 def test_tri_xattn_lambda_zero_equals_two_pathways(hip):
     """routing_gates.py:160,177-178: delta_scale == 0 must skip the delta pathway exactly; garbage
     (even NaN) in the delta tokens must not leak."""

@@ -140,6 +140,16 @@ class TorchRefBackend:
         p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
         out.copy_((p @ v).transpose(1, 2).reshape(b, n, c).to(out.dtype))
 
+    def attn2_fused(self, x, mcat, vw, bias, residual, out):
+        b, hw, c = x.shape
+        s = torch.einsum("bmc,bkc->bmk", x.float(), mcat.float())            # log2(e)/sqrt(d) folded in
+        pr = torch.softmax(s.view(b, hw, 24, 16) * math.log(2.0), dim=-1).view(b, hw, 384)
+        pr = pr.to(torch.float16).float()                                     # P is stored in fp16
+        y = torch.einsum("bmk,bnk->bmn", pr, vw.float())
+        if bias is not None:
+            y = y + bias.float()
+        out.copy_((y + residual.float()).to(out.dtype))
+
     def tri_xattn(self, q, kv, out, gates, lam, mode, heads):
         b, n, c = q.shape
         d = c // heads
