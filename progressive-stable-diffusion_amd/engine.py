@@ -35,6 +35,7 @@ VAE_CH = (128, 256, 512, 512)
 HEADS = 8
 GROUPS = 32
 N_CU = 256
+A2_MIN_TILES = int(os.environ.get("DADD_A2_MIN_TILES", "128"))   # fused attn2: minimum tiles per launch
 
 
 # ----------------------------------------------------------------------------- weight packing
@@ -239,7 +240,9 @@ class UNetPlan(_Plan):
         if self.fused_attn2:
             for site, c in self.sites:
                 hw = self._site_hw(site)
-                if hw % 128 == 0 and c % 320 == 0:
+                # one workgroup per 128-token tile: only worth it where the tiles fill a good part of the chip
+                # (B=4: the 64x64 sites, 128 tiles; at 32x32 / 16x16 the 32 / 8 tiles ran 6 % slower end to end)
+                if hw % 128 == 0 and c % 320 == 0 and batch * hw // 128 >= A2_MIN_TILES:
                     ap = f"{u}{site}.transformer_blocks.0.attn2"
                     self.a2[site] = dict(
                         wq=self.dev(sd[ap + ".to_q.weight"].float()), wo=self.dev(sd[ap + ".to_out.0.weight"].float()),
