@@ -35,7 +35,12 @@ VAE_CH = (128, 256, 512, 512)
 HEADS = 8
 GROUPS = 32
 N_CU = 256
-A2_MIN_TILES = int(os.environ.get("DADD_A2_MIN_TILES", "128"))   # fused attn2: minimum tiles per launch
+# attn2 folded into one kernel (csrc/attn2_fused.hip).  Correct and parity-green, but its first version (single
+# instruction stream, one workgroup per 128-token tile) measured 45 us at 64x64 against ~37 us for the three
+# kernels it replaces and far worse on the smaller maps (32 / 8 tiles), so it is OFF by default: opt in with
+# DADD_FUSED_ATTN2=1; DADD_A2_MIN_TILES sets the smallest launch (in tiles) that uses it.
+FUSED_ATTN2 = os.environ.get("DADD_FUSED_ATTN2", "0") == "1"
+A2_MIN_TILES = int(os.environ.get("DADD_A2_MIN_TILES", "128"))
 
 
 # ----------------------------------------------------------------------------- weight packing
@@ -235,13 +240,12 @@ class UNetPlan(_Plan):
         # ---- attn2 folded into ONE kernel per block (dadd_attn2_fused_f16): with 16 keys per pathway
         # q K^T = x (W_q K^T) and P V W_o^T = P (V W_o^T), so the step-invariant conditioning absorbs both
         # projections.  Sites whose map is smaller than one 128-token tile (8x8) keep the three-kernel path.
-        self.fused_attn2 = bool(use_routing_gates) and os.environ.get("DADD_NO_FUSED_ATTN2") is None
+        self.fused_attn2 = bool(use_routing_gates) and FUSED_ATTN2
         self.a2, self._a2_dirty, self._a2_lam = {}, True, None
         if self.fused_attn2:
             for site, c in self.sites:
                 hw = self._site_hw(site)
-                # one workgroup per 128-token tile: only worth it where the tiles fill a good part of the chip
-                # (B=4: the 64x64 sites, 128 tiles; at 32x32 / 16x16 the 32 / 8 tiles ran 6 % slower end to end)
+                # one workgroup per 128-token tile: sites with few tiles leave most of the chip idle
                 if hw % 128 == 0 and c % 320 == 0 and batch * hw // 128 >= A2_MIN_TILES:
                     ap = f"{u}{site}.transformer_blocks.0.attn2"
                     self.a2[site] = dict(

@@ -207,6 +207,25 @@ def test_config1_sampler_matches_oracle(full_sd, gates_on):
     assert di.max().item() < (3e-2 if gates_on else 0.1) and di.mean().item() < 4e-3
 
 
+def test_fused_attn2_sampler_matches_oracle(full_sd, monkeypatch):
+    """attn2 folded into one kernel (x (W_q K^T) -> 24 softmaxes -> P (V W_o^T)) at every eligible site (opt-in
+    path, off by default): 256x256, B=1, 4 steps, lambda=3, vs the oracle."""
+    from progressive_stable_diffusion_amd import engine as E
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    monkeypatch.setattr(E, "FUSED_ATTN2", True)
+    monkeypatch.setattr(E, "A2_MIN_TILES", 1)
+    mod = _module(full_sd, 256, 1)
+    assert len(mod.ddim_loop(1, 32).u.a2) >= 8, "fused sites expected at 32x32 and 16x16"
+    target, source = torch.tensor([3.0]), torch.tensor([0.0])
+    pix = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    lat = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        z = PIPE._ddim_sample_ip(mod, target.to(DEV), source.to(DEV), pix.to(DEV), 4, DEV, latents=lat, steer_scale=3.0)
+        feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
+        z_ref = OS.ddim_sample(full_sd, _ocfg(mod), target, source, feats, 4, lat, steer_scale=3.0)
+    assert (z.cpu() - z_ref).abs().max().item() < 5e-2
+
+
 def test_batched_sampler_matches_oracle(full_sd):
     """``_ddim_sample_batched`` (the data-augmentation / evaluation copy of the sampler): one structure
     image and one noise draw PER sample; 128x128, 4 steps, B=2, lambda=2."""
