@@ -22,14 +22,17 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 64, NS = 384, BN2 = 160;
-constexpr int A_BYTES = BM * BK * 2;          // 16 KB
+constexpr int BK = 64, NS = 384, BN2 = 160;
 constexpr int B1_BYTES = NS * BK * 2;         // 48 KB
-constexpr int STAGE1 = A_BYTES + B1_BYTES;    // 64 KB
 constexpr int P_STRIDE = 896;                 // bytes per P row (768 used)
-constexpr int P_BYTES = BM * P_STRIDE;        // 112 KB
 constexpr int B2_BYTES = BN2 * BK * 2;        // 20 KB
-constexpr int SMEM = P_BYTES + 2 * B2_BYTES;  // 152 KB  (>= 2 * STAGE1 = 128 KB)
+// BM = tokens per workgroup: 128, or 64 when 128-token tiles would leave half of the CUs idle
+template <int BM> constexpr int a_bytes() { return BM * BK * 2; }
+template <int BM> constexpr int stage1() { return a_bytes<BM>() + B1_BYTES; }
+template <int BM> constexpr int p_bytes() { return BM * P_STRIDE; }
+template <int BM> constexpr int smem_bytes() {
+  return (p_bytes<BM>() + 2 * B2_BYTES) > 2 * stage1<BM>() ? (p_bytes<BM>() + 2 * B2_BYTES) : 2 * stage1<BM>();
+}
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned OOB = 0x80000000u;
@@ -48,8 +51,13 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // halfs, 128-byt
   return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8;
 }
 
+template <int BM>
 __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MI = BM / 32;                  // 16-row fragments per wave (wave tile BM/2 rows)
+  constexpr int WMR = BM / 2;
+  constexpr int NXP = BM / 32;                 // x DMA pieces per wave
+  constexpr int A_BYTES = a_bytes<BM>(), STAGE1 = stage1<BM>(), P_BYTES = p_bytes<BM>();
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -67,9 +75,9 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
       __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((size_t)p.B * p.HW * C * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.mcat + (size_t)b * NS * C), 0, NS * C * 2, 0x00020000);
-  unsigned xv[4], mv[12];     // per-lane byte offsets of this wave's DMA pieces (8 rows x 128 B each)
+  unsigned xv[NXP], mv[12];     // per-lane byte offsets of this wave's DMA pieces (8 rows x 128 B each)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NXP; ++i) {
     const int row = (i * 4 + wave) * 8 + lrow;
     xv[i] = (unsigned)(((size_t)(m0 + row) * C + (lch ^ ((row >> 1) & 7)) * 8) * 2);
   }
@@ -82,22 +90,22 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
     char* sa = smem + stage * STAGE1 + wave * 1024;
     const unsigned ko = (unsigned)(kt * BK * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NXP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(sa + i * 4096), 16, xv[i], ko, 0, 0);
 #pragma unroll
     for (int j = 0; j < 12; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, (lptr_t)(sa + A_BYTES + j * 4096), 16, mv[j], ko, 0, 0);
   };
 
-  f4 acc[12][4];
+  f4 acc[12][MI];
 #pragma unroll
   for (int j = 0; j < 12; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
   int fa[2], fb[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    fa[s] = lds_off(wm * 64 + mc, s * 4 + fq) * 2;
+    fa[s] = lds_off(wm * WMR + mc, s * 4 + fq) * 2;
     fb[s] = A_BYTES + lds_off(wn * 192 + mc, s * 4 + fq) * 2;
   }
   issue1(0, 0);
@@ -108,15 +116,15 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
     const char* st = smem + (kt & 1) * STAGE1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      h8 xa[4], wb[12];
+      h8 xa[MI], wb[12];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const h8*>(st + fa[s] + i * 2048);
+      for (int i = 0; i < MI; ++i) xa[i] = *reinterpret_cast<const h8*>(st + fa[s] + i * 2048);
 #pragma unroll
       for (int j = 0; j < 12; ++j) wb[j] = *reinterpret_cast<const h8*>(st + fb[s] + j * 2048);
 #pragma unroll
       for (int j = 0; j < 12; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
     }
   }
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
 
   // ---------------------------------------------------------------- softmax per 16-column group, P -> LDS (fp16)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wm * 64 + i * 16 + mc;
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * WMR + i * 16 + mc;
     char* prow = smem + row * P_STRIDE;
     const int swz = (row >> 1) & 7;
 #pragma unroll
@@ -170,18 +178,18 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
   }
 
   // ---------------------------------------------------------------- phase 2: out = P VW^T + bias + residual
-  const int fp0 = (wm * 64 + mc) * P_STRIDE;            // P fragment row base (fragment i adds i*16 rows)
-  const int pswz = ((wm * 64 + mc) >> 1) & 7;           // (row + 16 i) >> 1 & 7 == (row >> 1) & 7
+  const int fp0 = (wm * WMR + mc) * P_STRIDE;           // P fragment row base (fragment i adds i*16 rows)
+  const int pswz = ((wm * WMR + mc) >> 1) & 7;           // (row + 16 i) >> 1 & 7 == (row >> 1) & 7
   const int swb = wn * 80 + mc;
   const int fv0 = (swb * 8 + (fq ^ ((swb >> 1) & 7))) * 16;
-  f4 acc2[5][4];
+  f4 acc2[5][MI];
   for (int it = 0; it < n_it2; ++it) {
     const int nt = it / nk2, kt = it - nt * nk2;
     if (kt == 0) {
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc2[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc2[j][i] = f4{0.f, 0.f, 0.f, 0.f};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // VW tile `it` landed (first time: P writes visible too)
@@ -189,22 +197,22 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
     const char* vt = smem + P_BYTES + (it & 1) * B2_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      h8 pa[4], wb[5];
+      h8 pa[MI], wb[5];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
         pa[i] = *reinterpret_cast<const h8*>(smem + fp0 + i * 16 * P_STRIDE + kt * 128 + (((s * 4 + fq) ^ pswz) << 4));
 #pragma unroll
       for (int j = 0; j < 5; ++j) wb[j] = *reinterpret_cast<const h8*>(vt + (fv0 ^ (s * 64)) + j * 2048);
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
           acc2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], pa[i], acc2[j][i], 0, 0, 0);
     }
     if (kt == nk2 - 1) {                               // epilogue of column tile nt
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const size_t m = (size_t)m0 + wm * 64 + i * 16 + mc;
+      for (int i = 0; i < MI; ++i) {
+        const size_t m = (size_t)m0 + wm * WMR + i * 16 + mc;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const int n = nt * BN2 + wn * 80 + j * 16 + g * 4;
@@ -223,16 +231,23 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
 
 }  // namespace
 
+int g_attn2_cus = 0;
+
 int dadd_init_attn2_fused() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fused_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fused_kernel<128>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<128>()));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fused_kernel<64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<64>()));
+  int dev = 0;
+  DADD_HIP(hipGetDevice(&dev));
+  DADD_HIP(hipDeviceGetAttribute(&g_attn2_cus, hipDeviceAttributeMultiprocessorCount, dev));
   return DADD_OK;
 }
 
 extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const float* bias,
                                     const void* residual, void* out, int B, int HW, int C, void* stream) {
   DADD_REQUIRE(x && mcat && vw && residual && out, "attn2_fused: null pointer");
-  DADD_REQUIRE(B > 0 && HW > 0 && HW % BM == 0, "attn2_fused: H*W=%d must be a multiple of %d", HW, BM);
+  DADD_REQUIRE(B > 0 && HW > 0 && HW % 128 == 0, "attn2_fused: H*W=%d must be a multiple of 128", HW);
   DADD_REQUIRE(C > 0 && C % BN2 == 0 && C % BK == 0, "attn2_fused: C=%d must be a multiple of 320", C);
   DADD_REQUIRE((size_t)B * HW * C * 2 < 0x7FF00000ull, "attn2_fused: activation larger than the 2 GiB buffer window");
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(mcat) && dadd_aligned16(vw) && dadd_aligned16(residual) &&
@@ -246,7 +261,12 @@ extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void*
   a.residual = static_cast<const half_t*>(residual);
   a.out = static_cast<half_t*>(out);
   a.B = B; a.HW = HW; a.C = C;
-  hipLaunchKernelGGL(attn2_fused_kernel, dim3(B * HW / BM), dim3(256), SMEM, static_cast<hipStream_t>(stream), a);
+  if (B * HW / 128 < g_attn2_cus)     // 128-token tiles would not fill the chip
+    hipLaunchKernelGGL(attn2_fused_kernel<64>, dim3(B * HW / 64), dim3(256), smem_bytes<64>(),
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(attn2_fused_kernel<128>, dim3(B * HW / 128), dim3(256), smem_bytes<128>(),
+                       static_cast<hipStream_t>(stream), a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
