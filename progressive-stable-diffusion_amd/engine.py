@@ -35,11 +35,10 @@ VAE_CH = (128, 256, 512, 512)
 HEADS = 8
 GROUPS = 32
 N_CU = 256
-# attn2 folded into one kernel (csrc/attn2_fused.hip).  Correct and parity-green, but its first version (single
-# instruction stream, one workgroup per 128-token tile) measured 45 us at 64x64 against ~37 us for the three
-# kernels it replaces and far worse on the smaller maps (32 / 8 tiles), so it is OFF by default: opt in with
-# DADD_FUSED_ATTN2=1; DADD_A2_MIN_TILES sets the smallest launch (in tiles) that uses it.
-FUSED_ATTN2 = os.environ.get("DADD_FUSED_ATTN2", "0") == "1"
+# attn2 folded into one kernel (csrc/attn2_fused.hip).  Used where one launch has at least A2_MIN_TILES 128-token
+# tiles (B=4: the 64x64 sites; same-box A/B +0.9 % end to end); on the smaller maps its 32 / 8 workgroups leave the
+# chip idle (-6 % when forced everywhere), so those keep to_q + xattn + to_out.  DADD_FUSED_ATTN2=0 switches it off.
+FUSED_ATTN2 = os.environ.get("DADD_FUSED_ATTN2", "1") == "1"
 A2_MIN_TILES = int(os.environ.get("DADD_A2_MIN_TILES", "128"))
 
 
