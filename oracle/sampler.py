@@ -104,10 +104,11 @@ def ddim_update(latents, eps, ac, t_int, t_prev_int, last, eta=0.0, noise=None):
 
 def ddim_sample(sd, cfg: OracleCfg, target, source, clip_features, sampling_steps, init_latents,
                 eta=0.0, image_scale=1.0, leace=None, steer_scale=0.0, guidance_scale=1.0,
-                trace=None):
+                trace=None, step_noise=None):
     """Whole sampler.  ``init_latents`` (B,4,S,S) replaces the device ``randn`` (:377-385).
 
-    ``trace``: optional list receiving (eps, latents) per step for step-wise parity tests.
+    ``trace``: optional list receiving (eps, latents) per step for step-wise parity tests;
+    ``step_noise`` (steps-1,B,4,S,S) replaces the per-step ``randn_like`` of the eta > 0 branch (:462-466).
     """
     do_cfg = (not cfg.use_routing_gates) and (guidance_scale != 1.0)
     T = cfg.num_train_timesteps
@@ -135,7 +136,9 @@ def ddim_sample(sd, cfg: OracleCfg, target, source, clip_features, sampling_step
         else:
             eps = unet(cond)
         last = i == sampling_steps - 1
-        noise = torch.randn_like(x) if (eta != 0.0 and not last) else None
+        noise = None
+        if eta != 0.0 and not last:
+            noise = torch.randn_like(x) if step_noise is None else step_noise[i].to(x)
         x = ddim_update(x, eps, ac, t_int, None if last else int(ts[i + 1]), last, eta, noise)
         if trace is not None:
             trace.append((eps, x.clone()))

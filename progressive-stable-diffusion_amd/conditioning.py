@@ -157,6 +157,21 @@ CLIP_VIT_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=
                     num_attention_heads=16, image_size=224, patch_size=14, projection_dim=768)
 
 
+def clip_config_from_state_dict(sd) -> dict:
+    """CLIP vision config read off the tensor shapes of an ``image_encoder.image_encoder.*`` slice (the reference
+    takes it from ``diff_cfg.image_encoder_path`` on the hub, image_encoder.py:34-42; offline the checkpoint is
+    the only source).  Head width is 64 in every released CLIP ViT."""
+    emb = "vision_model.embeddings."
+    hidden = sd[emb + "class_embedding"].shape[0]
+    patch = sd[emb + "patch_embedding.weight"].shape[-1]
+    n_pos = sd[emb + "position_embedding.weight"].shape[0]
+    layers = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("vision_model.encoder.layers."))
+    return dict(hidden_size=hidden, intermediate_size=sd["vision_model.encoder.layers.0.mlp.fc1.weight"].shape[0],
+                num_hidden_layers=layers, num_attention_heads=max(1, hidden // 64),
+                image_size=int(round((n_pos - 1) ** 0.5)) * patch, patch_size=patch,
+                projection_dim=sd["visual_projection.weight"].shape[0])
+
+
 class ImageEncoder:
     """Frozen CLIP vision tower.  The reference loads ``openai/clip-vit-large-patch14`` from the hub
     (image_encoder.py:34-42); offline the same architecture is built from its config with seeded
@@ -164,13 +179,21 @@ class ImageEncoder:
 
     def __init__(self, device, seed: int = 0, clip_config: Optional[dict] = None, state_dict=None):
         from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+        if clip_config is None and state_dict is not None:
+            clip_config = clip_config_from_state_dict(state_dict)
         cfg = CLIPVisionConfig(**(clip_config or CLIP_VIT_L14))
         rng = torch.random.get_rng_state()
         torch.manual_seed(seed)
         self.image_encoder = CLIPVisionModelWithProjection(cfg)
         torch.random.set_rng_state(rng)
         if state_dict is not None:
-            self.image_encoder.load_state_dict(state_dict, strict=False)
+            own = self.image_encoder.state_dict()
+            sd = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}   # buffer in old layouts
+            lacking = [k for k in own if k not in sd and not k.endswith("position_ids")]
+            extra = [k for k in sd if k not in own]
+            if lacking or extra:
+                raise KeyError(f"CLIP tower state dict mismatch: missing {lacking[:3]} unexpected {extra[:3]}")
+            self.image_encoder.load_state_dict(sd, strict=False)
         self.image_encoder.requires_grad_(False).eval().to(device=device, dtype=torch.float32)
         self.hidden_size = cfg.hidden_size
         self.projection_dim = cfg.projection_dim

@@ -142,11 +142,13 @@ class OrdinalUNet:
             raise ValueError(f"UNet cross_attention_dim mismatch: {c.cross_attention_dim} (from weights) "
                              f"vs {conditioning_dim} (config).")
         self._plan = plan
+        self._cond_ref, self._cond_ver, self._cond_gen = None, -1, -1
 
     def parameters(self) -> Iterator[torch.Tensor]:
         return iter(self._plan.keep)
 
     def __call__(self, latents, timesteps, cond_embed):
+        cond_in = cond_embed                  # identity of the caller's tensor (views below are new objects)
         if cond_embed.ndim == 2:
             cond_embed = cond_embed.unsqueeze(1)
         elif cond_embed.ndim != 3:
@@ -157,13 +159,24 @@ class OrdinalUNet:
             timesteps = timesteps.view(-1)
         plan = self._plan
         be = plan.be
+        # dtype / device / shape normalisation runs on torch's CURRENT stream, i.e. before wait_current()
+        # orders the backend stream behind it (a scalar, CPU or non-fp32 input is produced here)
+        timesteps = timesteps.to(device=latents.device, dtype=torch.long).reshape(-1)
+        if timesteps.shape[0] == 1:
+            timesteps = timesteps.expand(plan.B)
+        timesteps = timesteps.contiguous()
+        latents = latents.float().contiguous()
+        # Conditioning tensors are step-invariant: re-project only when the caller passes a new one.  The cache
+        # HOLDS the tensor (an address can be recycled by the allocator) and is tied to the plan's conditioning
+        # generation, which every set_cond() — e.g. a sampler run on the same plan — advances.
+        fresh = not (cond_in is self._cond_ref and cond_in._version == self._cond_ver
+                     and plan.cond_gen == self._cond_gen)
+        if fresh:
+            cond_embed = cond_embed.to(device=latents.device)
         be.wait_current()
-        # conditioning tensors are step-invariant: re-project only when the caller passes a new one
-        key = (cond_embed.data_ptr(), cond_embed._version, tuple(cond_embed.shape))
-        fresh = key != getattr(self, "_cond_key", None)
-        self._cond_key = key
-        eps = plan.forward(latents, timesteps.to(latents.device), cond_embed if fresh else None,
-                           lam=self.unet.delta_scale())
+        eps = plan.forward(latents, timesteps, cond_embed if fresh else None, lam=self.unet.delta_scale())
+        if fresh:
+            self._cond_ref, self._cond_ver, self._cond_gen = cond_in, cond_in._version, plan.cond_gen
         be.release_to_current()
         return eps
 
@@ -214,7 +227,8 @@ class SDVAE:
 class DiffusionModuleWithIP:
     def __init__(self, cfg: Any, state_dict: Optional[Dict[str, torch.Tensor]] = None, *,
                  device=None, seed: int = 0, batch_size: Optional[int] = None,
-                 clip_config: Optional[dict] = None, backend=None, warm_start_dis: bool = True):
+                 clip_config: Optional[dict] = None, backend=None, warm_start_dis: bool = True,
+                 _strict: Optional[bool] = None, _report=None):
         from .backend import HipBackend
         self.cfg = cfg
         self.diff_cfg = diff_cfg_from(cfg)
@@ -226,6 +240,11 @@ class DiffusionModuleWithIP:
         routing = dc.use_routing_gates
         gates = {"anatomy": dc.gate_init_anatomy, "disease": dc.gate_init_disease, "both": (0.5, 0.5)}
         emb = cfg.model.ordinal_embedder
+        clip_pref = "image_encoder.image_encoder."
+        if clip_config is None and state_dict is not None and (clip_pref + "visual_projection.weight") in state_dict:
+            from .conditioning import clip_config_from_state_dict     # tower geometry from the file's tensors
+            clip_config = clip_config_from_state_dict(
+                {k[len(clip_pref):]: v for k, v in state_dict.items() if k.startswith(clip_pref)})
         shapes = dict(W.unet_shapes(routing_gates=routing))
         shapes.update(W.vae_shapes(encoder=False))
         shapes.update(W.conditioning_shapes(
@@ -234,12 +253,21 @@ class DiffusionModuleWithIP:
             clip_proj=(clip_config or {}).get("projection_dim", 768),
             projection_plus=dc.use_image_projection_plus, purifier=dc.use_feature_purifier,
             purifier_ff_mult=dc.purifier_ff_mult))
+        user_sd = state_dict is not None
         if state_dict is None:
             state_dict = W.init_state_dict(shapes, seed, gates=gates, warm_start_dis=warm_start_dis,
                                            aoe_delta_scale=getattr(emb.aoe, "delta_scale", 0.1))
-        missing = [k for k in shapes if k not in state_dict]
-        if missing:
-            raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        if _strict is None:          # direct construction: every tensor of the inventory must be there
+            missing = [k for k in shapes if k not in state_dict]
+            if missing:
+                raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        else:                        # load_from_checkpoint: load_state_dict(strict=...) semantics + a report
+            from . import checkpoint as CK
+            clip_keys = {k: tuple(v.shape) for k, v in state_dict.items() if k.startswith("image_encoder.")}
+            state_dict = CK.reconcile(dict(state_dict), {**shapes, **clip_keys}, strict=_strict, seed=seed,
+                                      init_kwargs=dict(gates=gates, aoe_delta_scale=getattr(emb.aoe, "delta_scale", 0.1)),
+                                      report=_report)
+        self.load_report = _report
         self._sd = state_dict
         self.latent_side = cfg.dataset.image_size // 8
         self.batch_size = batch_size or 1
@@ -251,7 +279,16 @@ class DiffusionModuleWithIP:
 
         self.ordinal_embedder = AdditiveOrdinalEmbedder(
             state_dict, self.device, emb.num_classes, cfg.model.embedding_dim, dc.num_aoe_tokens)
-        self.image_encoder = ImageEncoder(self.device, seed=seed, clip_config=clip_config)
+        # The reference keeps the CLIP tower as an nn.Module child, so a Lightning state_dict carries
+        # ``image_encoder.image_encoder.*``.  Use those tensors when present; a caller-supplied
+        # state dict WITHOUT them gets a seeded random tower and a loud warning (bench / tests only).
+        clip_sd = {k[len(clip_pref):]: v for k, v in state_dict.items() if k.startswith(clip_pref)}
+        if not clip_sd and user_sd:
+            import warnings
+            warnings.warn("state dict has no 'image_encoder.image_encoder.*' tensors: the CLIP tower is SEEDED RANDOM "
+                          "(anatomy tokens are noise for a real checkpoint)", RuntimeWarning, stacklevel=2)
+        self.image_encoder = ImageEncoder(self.device, seed=seed, clip_config=clip_config,
+                                          state_dict=clip_sd or None)
         proj_cls = ImageProjectionPlus if dc.use_image_projection_plus else ImageProjection
         self.image_projection = proj_cls(state_dict, self.device, dc.num_image_tokens)
         self.feature_purifier = (FeaturePurifier(state_dict, self.device, dc.purifier_num_heads)
@@ -288,19 +325,24 @@ class DiffusionModuleWithIP:
     # ---- reference protocol -----------------------------------------------------------------------
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, cfg=None, weights_only=False, strict=False,
-                             map_location=None, **kw):
-        """Lightning ``.ckpt`` / plain state-dict loader.  Only loaders that execute nothing from the
-        file are used (``weights_only=True`` / safetensors) whatever the caller passes."""
-        path = str(checkpoint_path)
-        if path.endswith(".safetensors"):
-            from safetensors.torch import load_file
-            sd = load_file(path)
-        else:
-            blob = torch.load(path, map_location="cpu", weights_only=True)
-            sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+                             map_location=None, *, which: str = "ema", **kw):
+        """Lightning ``.ckpt`` / plain state-dict / safetensors loader (checkpoint.py).
+        ``state_dict`` of a file saved by the EMA callback holds the averaged weights (``which="ema"``, what the
+        reference's inference loads), ``current_model_state`` the raw ones (``which="raw"``).  ``strict=False``
+        (the reference's call, inference_pipeline_ip.py:587-592) tolerates missing / unexpected keys and reports
+        them in ``module.load_report``.  Only loaders that execute nothing from the file are used, whatever
+        ``weights_only`` says."""
+        from . import checkpoint as CK
+        from .config import to_attr
+        sd, rep, blob = CK.load_state(str(checkpoint_path), which=which)
         if cfg is None:
-            raise ValueError("cfg is required (the reference stores it as a hyper-parameter)")
-        return cls(cfg, state_dict={k: v.float() for k, v in sd.items()}, **kw)
+            hp = blob.get("hyper_parameters") if isinstance(blob, dict) else None
+            if isinstance(hp, dict) and isinstance(hp.get("cfg"), dict):
+                cfg = to_attr(hp["cfg"])
+            else:
+                raise ValueError("cfg is required (the file carries no plain-dict hyper_parameters['cfg'])")
+        mod = cls(cfg, state_dict=sd, _strict=bool(strict), _report=rep, **kw)
+        return mod
 
     def to(self, *args, **kwargs):
         for a in args:

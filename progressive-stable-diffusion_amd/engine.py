@@ -236,6 +236,7 @@ class UNetPlan(_Plan):
                              for _ in range(2)]                     # [cond, uncond]
         self.cond16 = be.zeros((batch, 1, self.T, 768), F16)
         self.kv_slot = 0
+        self.cond_gen = 0      # advanced by every set_cond(): callers that cache projections key on it
         # ---- attn2 folded into ONE kernel per block (dadd_attn2_fused_f16): with 16 keys per pathway
         # q K^T = x (W_q K^T) and P V W_o^T = P (V W_o^T), so the step-invariant conditioning absorbs both
         # projections.  Sites whose map is smaller than one 128-token tile (8x8) keep the three-kernel path.
@@ -430,6 +431,7 @@ class UNetPlan(_Plan):
         self.be.copy_(self.cond16, cond)
         for site, _ in self.sites:
             self.be.igemm(self.cond16, self.kv_w[site], self.kv[site][slot], taps=1, pad=0)
+        self.cond_gen += 1
         if slot == 0:
             self._a2_dirty = True
 

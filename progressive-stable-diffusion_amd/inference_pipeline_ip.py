@@ -154,10 +154,11 @@ def _ddim_sample_ip(module: DiffusionModuleWithIP, target_labels: Tensor, source
                     eta: float = 0.0, image_scale: float = 1.0, leace: Optional[dict] = None,
                     steer_scale: float = 0.0, guidance_scale: float = 1.0, *,
                     latents: Optional[Tensor] = None, use_graph: bool = True,
-                    trace: Optional[list] = None) -> Tensor:
+                    trace: Optional[list] = None, step_noise: Optional[Tensor] = None) -> Tensor:
     """(:321-470).  Keyword-only extras: ``latents`` injects the initial noise (B,4,S,S) instead of
     drawing it on the device (CPU and device RNG streams differ — parity tests need this);
-    ``use_graph`` / ``trace`` select eager execution and per-step capture of (eps, latents)."""
+    ``use_graph`` / ``trace`` select eager execution and per-step capture of (eps, latents);
+    ``step_noise`` (steps-1,B,4,S,S) injects the per-step noise of the eta > 0 branch (:462-466)."""
     use_routing_gates = getattr(module.diff_cfg, "use_routing_gates", True)
     do_cfg = (not use_routing_gates) and (guidance_scale != 1.0)
     num_samples = target_labels.shape[0]
@@ -184,7 +185,8 @@ def _ddim_sample_ip(module: DiffusionModuleWithIP, target_labels: Tensor, source
     _set_delta_scale_on_processors(module, steer_scale)
 
     if eta != 0.0:
-        return _ddim_stochastic(module, latents, timesteps, embed_cond, embed_uncond, guidance_scale, eta)
+        return _ddim_stochastic(module, latents, timesteps, embed_cond, embed_uncond, guidance_scale, eta,
+                                step_noise=step_noise)
 
     loop = module.ddim_loop(num_samples, side)
     plan, be = loop.u, loop.be
@@ -227,8 +229,8 @@ def _decode_latents(module: DiffusionModuleWithIP, latents: Tensor) -> Tensor:
     return _latents_to_images(module, latents).float().cpu()
 
 
-def _ddim_stochastic(module, latents, timesteps, cond, uncond, guidance_scale, eta):
-    """eta > 0 (:457-468): per-step engine calls, update in torch (device RNG noise)."""
+def _ddim_stochastic(module, latents, timesteps, cond, uncond, guidance_scale, eta, step_noise=None):
+    """eta > 0 (:457-468): per-step engine calls, update in torch (device RNG noise unless injected)."""
     ac = module.alphas_cumprod
     n = timesteps.shape[0]
     for i in range(n):
@@ -244,8 +246,9 @@ def _ddim_stochastic(module, latents, timesteps, cond, uncond, guidance_scale, e
             return x0
         a_p = ac[int(timesteps[i + 1])].to(latents.dtype)
         sigma = eta * torch.sqrt((1 - a_p) / (1 - a_t) * (1 - a_t / a_p))
-        latents = (torch.sqrt(a_p) * x0 + torch.sqrt(1 - a_p - sigma ** 2) * eps
-                   + sigma * torch.randn_like(latents))
+        noise = (torch.randn_like(latents) if step_noise is None
+                 else step_noise[i].to(device=latents.device, dtype=latents.dtype))
+        latents = torch.sqrt(a_p) * x0 + torch.sqrt(1 - a_p - sigma ** 2) * eps + sigma * noise
     return latents
 
 

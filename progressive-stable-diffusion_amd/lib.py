@@ -70,8 +70,9 @@ _lib: Optional[C.CDLL] = None
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into ``libdadd_hip.so`` (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "dadd_common.h"), os.path.join(CSRC, "igemm_args.h"),
-                   os.path.join(os.path.dirname(_HERE), "include", "dadd_hip.h")]
+    import glob
+    deps = sorted(set(srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))) + \
+        [os.path.join(os.path.dirname(_HERE), "include", "dadd_hip.h")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
