@@ -49,31 +49,125 @@ def parse():
 
 
 def cpu_baseline(sd, image_size):
-    """The oracle (CPU port of the reference path) on a BOUNDED sample: 1 UNet eps call + 1 VAE
-    decode at B=1 on a 256x256 image (BASELINE configs[0] shape; ~20-40 s of CPU work), scaled to
-    the benchmark resolution by the analytic FLOP ratio and to 50 steps linearly — stated in `sample`."""
+    """The oracle (CPU port of the reference path: eager fp32 torch, materialised attention) on the GPU box's
+    host cores, the procedure of SURVEY.md §8d / BASELINE.md §3:
+      * C1 (BASELINE configs[0]) timed IN FULL, both readings of "guidance 3.0": 1 image, 256x256, 10 DDIM steps +
+        decode — (i) routing gates + steer lambda = 3.0, (ii) baseline processors + CFG g = 3.0 (two UNet calls/step);
+      * C2 (the metric's config) on a BOUNDED sample: one warm-up eps call, then 2 DDIM steps + 1 VAE decode at
+        512x512, B = 1; per image = 25 x (2-step time) + decode time (extrapolated linearly, stated).
+    `value` is the C2 figure in the metric's unit."""
+    from oracle import sampler as OS
     from oracle.sd_unet import unet_forward
     from oracle.sd_vae import vae_decode
     cores = min(os.cpu_count() or 1, 64)       # eager fp32 torch stops scaling well before 64 threads
     torch.set_num_threads(cores)
-    flops = {256: (178.7, 622.2), 512: (800.8, 2514.5), 768: (2144.0, 5754.3)}   # GF/sample, SURVEY App. B
-    s = 32
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, 4, s, s, generator=g)
-    cond = torch.randn(1, 48, 768, generator=g) * 0.5
+    feats = torch.randn(1, 257, 1024, generator=g)
+    c1 = {}
     with torch.no_grad():
+        for tag, gates_on, kw in (("gates_lambda3", True, dict(steer_scale=3.0)), ("baseline_cfg3", False, dict(guidance_scale=3.0))):
+            ocfg = OS.OracleCfg(image_size=256, use_routing_gates=gates_on)
+            lat = torch.randn(1, 4, 32, 32, generator=g)
+            t0 = time.perf_counter()
+            z = OS.ddim_sample(sd, ocfg, torch.tensor([3.0]), torch.tensor([0.0]), feats, 10, lat, **kw)
+            OS.latents_to_images(sd, ocfg, z)
+            c1[tag] = time.perf_counter() - t0
+        side = image_size // 8
+        ocfg = OS.OracleCfg(image_size=image_size)
+        _, ac, _, _ = OS.noise_schedule(ocfg)
+        cond = OS.prepare_conditioning(sd, ocfg, torch.tensor([3.0]), torch.tensor([2.0]), feats)
+        x = torch.randn(1, 4, side, side, generator=g)
+        ts = OS.ddim_timesteps(1000, 50)
+        unet_forward(sd, x, ts[:1], cond, delta_scale=3.0)                     # warm-up (allocator, thread pool)
         t0 = time.perf_counter()
-        unet_forward(sd, x, torch.tensor([500]), cond, delta_scale=3.0)
-        t_unet = time.perf_counter() - t0
+        for i in range(2):
+            eps = unet_forward(sd, x, ts[i:i + 1], cond, delta_scale=3.0)
+            x = OS.ddim_update(x, eps, ac, int(ts[i]), int(ts[i + 1]), False)
+        t_steps = time.perf_counter() - t0
         t0 = time.perf_counter()
-        vae_decode(sd, x)
+        vae_decode(sd, x / ocfg.latent_scale)
         t_dec = time.perf_counter() - t0
-    fu, fd = flops.get(image_size, flops[512])
-    per_image = 50 * t_unet * fu / flops[256][0] + t_dec * fd / flops[256][1]
+    per_image = 25.0 * t_steps + t_dec
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (fp32 torch, {cores} threads): 1 UNet eps call at B=1, 256x256 = {t_unet:.2f}s, "
-                      f"1 VAE decode at 256x256 = {t_dec:.2f}s; scaled to {image_size}x{image_size} by the analytic "
-                      f"FLOP ratio ({fu}/{flops[256][0]} and {fd}/{flops[256][1]} GF) and to 50 steps linearly (extrapolated)"}
+            "c1_seconds_per_image": c1, "c1_images_per_sec": {k: 1.0 / v for k, v in c1.items()},
+            "sample": f"CPU oracle (fp32 torch, {cores} threads).  C1 timed in full (1 image, 256x256, 10 DDIM steps + decode): "
+                      f"gates+lambda=3 {c1['gates_lambda3']:.1f}s, baseline+CFG g=3 {c1['baseline_cfg3']:.1f}s.  C2 ({image_size}x{image_size}, B=1): "
+                      f"1 warm-up eps call, then 2 DDIM steps = {t_steps:.2f}s and 1 VAE decode = {t_dec:.2f}s; per image = 25 x "
+                      f"{t_steps:.2f} + {t_dec:.2f} = {per_image:.1f}s (50 steps extrapolated linearly from 2)"}
+
+
+PEAK_HBM_GBS = 8000.0              # HBM3E peak, MI355X_MICROARCH.md chip table
+
+
+def kernel_table(records, n_steps):
+    """Per-kernel-name summary of a list of (name, us, flop, bytes) launch records — the live equivalent of a
+    ``rocprofv3 --kernel-trace --stats`` summary (same clock: the dispatch packets' begin/end timestamps)."""
+    tab = {}
+    for name, us, flop, byt in records:
+        t = tab.setdefault(name, {"name": name, "calls": 0, "us": 0.0, "flop": 0.0, "bytes": 0.0})
+        t["calls"] += 1
+        t["us"] += us
+        t["flop"] += flop
+        t["bytes"] += byt
+    total = sum(t["us"] for t in tab.values()) or 1.0
+    rows = sorted(tab.values(), key=lambda t: -t["us"])
+    for t in rows:
+        t["share"] = t["us"] / total
+        t["avg_us"] = t["us"] / t["calls"]
+        t["calls_per_step"] = t["calls"] / n_steps
+        t["tflops"] = t["flop"] / (t["us"] * 1e-6) / 1e12 if t["flop"] > 0 else None
+        t["gbs"] = t["bytes"] / (t["us"] * 1e-6) / 1e9
+    return rows, total
+
+
+def live_roofline(mod, a, side, lat, dev, n_steps=2):
+    """Roofline of the kernel with the largest share of GPU time in the UNet step, measured live: right after the
+    timed region the same step is launched eagerly ``n_steps`` times (a graph replay cannot carry per-kernel
+    events) with every launch's own begin/end timestamps recorded (hipExtLaunchKernelGGL event pair = the clock of
+    rocprofv3's kernel trace, so ``avg_launch_us`` is directly comparable with the AverageNs column of the
+    committed profiles/*_kernel_stats.csv).  achieved = sum of algorithmic flop (2*M*N*K) or bytes over the
+    launches of that kernel / sum of their durations."""
+    loop = mod.ddim_loop(a.batch, side)
+    be = loop.be
+    with torch.no_grad():    # same state as the timed passes: cond projected, tables prepared
+        be.copy_(loop.u.lat_in, lat.to(dev))
+        be.zero_(loop.step)
+        loop._one_step(a.steer_scale, False, 1.0)      # warm: the eager path's first launch of each kernel
+        be.synchronize()
+        be.prof_begin()
+        for _ in range(n_steps):
+            loop._one_step(a.steer_scale, False, 1.0)
+        rec = be.prof_end()
+    rows, total_us = kernel_table(rec, n_steps)
+    if not rows:
+        return None
+    dom = rows[0]
+    mfma = dom["tflops"] is not None
+    ach = dom["tflops"] if mfma else dom["gbs"]
+    peak = PEAK_F16_TFLOPS if mfma else PEAK_HBM_GBS
+    traffic = traffic_src = None
+    try:    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            tj = json.load(f)
+        if tj.get("dominant", {}).get("kernel", "").replace(" ", "") == dom["name"].replace(" ", ""):
+            traffic, traffic_src = tj["dominant"]["traffic_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc)"
+    except (OSError, KeyError, ValueError):
+        pass
+    gemm = [t for t in rows if t["tflops"] is not None]
+    return {"bound": "mfma" if mfma else "hbm", "kernel": dom["name"], "achieved": ach, "peak": peak,
+            "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / peak, "traffic": traffic,
+            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "share_of_step_gpu_time": dom["share"], "launches_per_step": dom["calls_per_step"],
+            "avg_launch_us": dom["avg_us"],
+            "algorithmic_per_launch": (dom["flop"] if mfma else dom["bytes"]) / dom["calls"],
+            "timing": "per-launch begin/end timestamps of the dispatch (hipExtLaunchKernelGGL events) over an eager "
+                      f"replay of {n_steps} steps right after the timed region; same clock as rocprofv3 --kernel-trace",
+            "step_kernel_us": total_us / n_steps, "step_launches": len(rec) / n_steps,
+            "all_mfma_kernels_tflops": sum(t["flop"] for t in gemm) / (sum(t["us"] for t in gemm) * 1e-6) / 1e12,
+            "top_kernels": [{"name": t["name"], "share": round(t["share"], 4), "calls_per_step": t["calls_per_step"],
+                             "avg_us": round(t["avg_us"], 2),
+                             "tflops": None if t["tflops"] is None else round(t["tflops"], 1),
+                             "gbs": round(t["gbs"], 1)} for t in rows[:10]]}
 
 
 def main():
@@ -135,56 +229,7 @@ def main():
 
     roof = None
     if not a.no_roofline:
-        loop = mod.ddim_loop(a.batch, side)
-        be = loop.be
-        with torch.no_grad():    # same state as the timed passes: cond projected, tables prepared
-            be.copy_(loop.u.lat_in, lat.to(dev))
-            be.zero_(loop.step)
-            be.synchronize()
-            be.prof_begin(2)          # exactly igemm_dma_kernel<160,false,false,true>: one row of rocprofv3 --stats
-            for _ in range(2):
-                loop._one_step(a.steer_scale, False, 1.0)
-            st = be.prof_end()
-            be.prof_begin(3)          # exactly conv3x3_halo_kernel<64>
-            for _ in range(2):
-                loop._one_step(a.steer_scale, False, 1.0)
-            halo = be.prof_end()
-            be.prof_begin(1)          # every implicit-GEMM launch (both kernels, all tile shapes)
-            for _ in range(2):
-                loop._one_step(a.steer_scale, False, 1.0)
-            fam = be.prof_end()
-            be.synchronize()
-            ovh = be.prof_event_overhead_ms()   # what the two event records cost with no kernel between them
-        if st["launches"] > 0 and st["ms"] > 0:
-            raw_us = st["ms"] * 1e3 / st["launches"]
-            st["ms"] = max(st["ms"] - ovh * st["launches"], 1e-6)
-            fam["ms"] = max(fam["ms"] - ovh * fam["launches"], 1e-6)
-            halo["ms"] = max(halo["ms"] - ovh * halo["launches"], 1e-6)
-            ach = st["flop"] / (st["ms"] * 1e-3) / 1e12
-            fam_ach = fam["flop"] / (fam["ms"] * 1e-3) / 1e12
-            # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB), which a
-            # running program cannot collect on itself: the committed summary of scripts/pmc_traffic.sh is quoted
-            traffic = traffic_src = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
-                    dom = json.load(f)["dominant"]
-                traffic, traffic_src = dom["traffic_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc)"
-            except (OSError, KeyError, ValueError):
-                pass
-            roof = {"bound": "mfma", "kernel": "igemm_dma_kernel<160,false,false,true> (wave-specialised LDS-DMA implicit GEMM: largest share of GPU time)",
-                    "achieved": ach, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
-                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                    "launches_per_step": st["launches"] // 2,
-                    "avg_launch_us": st["ms"] * 1e3 / st["launches"],
-                    "avg_launch_us_incl_event_overhead": raw_us, "event_pair_overhead_us": ovh * 1e3,
-                    "flop_per_launch_avg": st["flop"] / st["launches"],
-                    "share_of_step_flop": st["flop"] / (2 * 800.8e9 * a.batch) if a.image_size == 512 else None,
-                    "conv3x3_halo_kernel<64>": {"achieved": halo["flop"] / (halo["ms"] * 1e-3) / 1e12 if halo["launches"] else None,
-                                                "frac": halo["flop"] / (halo["ms"] * 1e-3) / 1e12 / PEAK_F16_TFLOPS if halo["launches"] else None,
-                                                "launches_per_step": halo["launches"] // 2,
-                                                "avg_launch_us": halo["ms"] * 1e3 / max(halo["launches"], 1)},
-                    "all_igemm_launches": {"achieved": fam_ach, "launches_per_step": fam["launches"] // 2,
-                                           "avg_launch_us": fam["ms"] * 1e3 / fam["launches"]}}
+        roof = live_roofline(mod, a, side, lat, dev)
 
     if rank == 0:
         images = n_total * a.steps

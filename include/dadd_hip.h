@@ -163,16 +163,17 @@ int dadd_graph_end(void* stream, void** graph_exec_out);
 int dadd_graph_launch(void* graph_exec, void* stream);
 int dadd_graph_destroy(void* graph_exec);
 
-/* ---- in-library HIP-event timing of one kernel family (bench.py roofline) -------------------
- * kind 1 = every implicit GEMM / conv, kind 2 = only igemm_dma_kernel<160,false,false,true> (the kernel
- * with the largest share of GPU time in the UNet step), kind 3 = only conv3x3_halo_kernel<64>.  While
- * enabled (eager launches only, never during capture) every launch of that family is bracketed by events
- * on its own stream.  dadd_prof_end fills out[0]=launches, out[1]=total ms, out[2]=total algorithmic
- * flop (2*M*N*K). */
-int dadd_prof_begin(int kind);
-int dadd_prof_end(double out[3]);
-/* median interval (ms) of an empty event pair on `stream`: subtracted per launch by bench.py */
-int dadd_prof_event_overhead(void* stream, double* out_ms);
+/* ---- per-kernel timing of eager launches (bench.py roofline, scripts/step_profile.py) -----------
+ * Between dadd_prof_begin() and dadd_prof_end() every kernel the library launches (eager launches only,
+ * never during stream capture) is issued with a start/stop event pair attached to its dispatch packet
+ * (hipExtLaunchKernelGGL): the pair reads the kernel's own begin/end timestamps, the clock rocprofv3's
+ * kernel trace reads, so the time excludes queue gaps.  dadd_prof_end synchronises and returns the number of
+ * recorded launches; dadd_prof_record(i) gives launch i in issue order: *name = kernel name as rocprofv3
+ * prints it (static string), out[0] = milliseconds, out[1] = algorithmic flop (2*M*N*K for the matrix
+ * kernels, 0 otherwise), out[2] = algorithmic bytes (compulsory HBM reads + writes). */
+int dadd_prof_begin(void);
+int dadd_prof_end(int* n_records);
+int dadd_prof_record(int i, const char** name, double out[3]);
 
 #ifdef __cplusplus
 }

@@ -189,16 +189,17 @@ class HipBackend:
     def graph_destroy(self, g):
         L.check(self.lib.dadd_graph_destroy(g))
 
-    def prof_begin(self, kind=1):
-        L.check(self.lib.dadd_prof_begin(kind))
+    def prof_begin(self):
+        """Start recording every kernel launch of the library (eager launches only)."""
+        L.check(self.lib.dadd_prof_begin())
 
     def prof_end(self):
-        out = (C.c_double * 3)()
-        L.check(self.lib.dadd_prof_end(out))
-        return {"launches": int(out[0]), "ms": out[1], "flop": out[2]}
-
-    def prof_event_overhead_ms(self):
-        """Median interval of an empty HIP-event pair on the backend stream."""
-        out = C.c_double(0.0)
-        L.check(self.lib.dadd_prof_event_overhead(self.s, C.byref(out)))
-        return out.value
+        """-> list of (kernel name, microseconds, algorithmic flop, algorithmic bytes) in issue order; the time
+        is the dispatch's own begin/end timestamp pair (what rocprofv3's kernel trace reports)."""
+        n = C.c_int(0)
+        L.check(self.lib.dadd_prof_end(C.byref(n)))
+        out, name, vals = [], C.c_char_p(), (C.c_double * 3)()
+        for i in range(n.value):
+            L.check(self.lib.dadd_prof_record(i, C.byref(name), vals))
+            out.append((name.value.decode(), vals[0] * 1e3, vals[1], vals[2]))
+        return out

@@ -15,13 +15,18 @@ int dadd_init_attn2_fused();
 namespace {
 thread_local char g_err[512] = "";
 
+struct ProfRec {
+  const char* name;
+  double flop, bytes;
+};
 struct ProfState {
-  int kind = 0;
-  std::vector<hipEvent_t> ev;  // pairs (start, stop)
-  std::vector<double> flop;
-  size_t used = 0;
+  std::vector<hipEvent_t> ev;  // pairs (start, stop), reused across sessions
+  std::vector<ProfRec> rec;
+  std::vector<float> ms;       // filled by dadd_prof_end
 } g_prof;
 }  // namespace
+
+int g_dadd_prof_on = 0;
 
 void dadd_set_error(const char* fmt, ...) {
   va_list ap;
@@ -30,24 +35,17 @@ void dadd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-bool dadd_prof_active(int kind) { return g_prof.kind == kind; }
-
-void dadd_prof_pre(hipStream_t s) {
-  if (g_prof.used + 2 > g_prof.ev.size()) {
-    for (int i = 0; i < 2; ++i) {
-      hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) return;
-      g_prof.ev.push_back(e);
-    }
+bool dadd_prof_slot(const DaddLaunchTag& tag, hipEvent_t* e0, hipEvent_t* e1) {
+  const size_t i = g_prof.rec.size();
+  while (g_prof.ev.size() < 2 * (i + 1)) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return false;
+    g_prof.ev.push_back(e);
   }
-  (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-}
-
-void dadd_prof_post(hipStream_t s, double flop) {
-  if (g_prof.used + 2 > g_prof.ev.size()) return;
-  (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
-  g_prof.used += 2;
-  g_prof.flop.push_back(flop);
+  *e0 = g_prof.ev[2 * i];
+  *e1 = g_prof.ev[2 * i + 1];
+  g_prof.rec.push_back(ProfRec{tag.name, tag.flop, tag.bytes});
+  return true;
 }
 
 extern "C" {
@@ -78,7 +76,7 @@ int dadd_device_info(int device, int64_t out[4]) {
 }
 
 int dadd_graph_begin(void* stream) {
-  DADD_REQUIRE(g_prof.kind == 0, "graph_begin: profiling is active");
+  DADD_REQUIRE(g_dadd_prof_on == 0, "graph_begin: profiling is active");
   DADD_HIP(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
   return DADD_OK;
 }
@@ -109,55 +107,37 @@ int dadd_graph_destroy(void* graph_exec) {
   return DADD_OK;
 }
 
-int dadd_prof_begin(int kind) {
-  DADD_REQUIRE(kind >= 1 && kind <= 3, "prof_begin: unknown kernel family %d", kind);
-  g_prof.kind = kind;
-  g_prof.used = 0;
-  g_prof.flop.clear();
+int dadd_prof_begin(void) {
+  g_prof.rec.clear();
+  g_prof.ms.clear();
+  g_dadd_prof_on = 1;
   return DADD_OK;
 }
 
-int dadd_prof_end(double out[3]) {
-  DADD_REQUIRE(out != nullptr, "prof_end: null out");
-  if (g_prof.kind == 0) {
+int dadd_prof_end(int* n_records) {
+  if (!g_dadd_prof_on) {
     dadd_set_error("prof_end without prof_begin");
     return DADD_ESTATE;
   }
-  g_prof.kind = 0;
-  double ms = 0.0, flop = 0.0;
-  const size_t n = g_prof.used / 2;
-  if (n > 0) DADD_HIP(hipEventSynchronize(g_prof.ev[g_prof.used - 1]));
+  g_dadd_prof_on = 0;
+  const size_t n = g_prof.rec.size();
+  g_prof.ms.assign(n, 0.f);
+  if (n > 0) DADD_HIP(hipEventSynchronize(g_prof.ev[2 * n - 1]));
   for (size_t i = 0; i < n; ++i) {
-    float t = 0.f;
-    DADD_HIP(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
-    ms += t;
-    flop += g_prof.flop[i];
+    DADD_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    DADD_HIP(hipEventElapsedTime(&g_prof.ms[i], g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
   }
-  out[0] = (double)n;
-  out[1] = ms;
-  out[2] = flop;
+  if (n_records) *n_records = (int)n;
   return DADD_OK;
 }
 
-// Median interval of an EMPTY (start, stop) event pair on `stream`: what the two hipEventRecord barrier
-// packets cost by themselves.  bench.py subtracts it from every bracketed launch so that the live
-// per-launch time is comparable with rocprofv3's kernel-only duration.
-int dadd_prof_event_overhead(void* stream, double* out_ms) {
-  DADD_REQUIRE(out_ms != nullptr, "prof_event_overhead: null out");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  constexpr int N = 33;
-  hipEvent_t ev[2 * N];
-  for (auto& e : ev) DADD_HIP(hipEventCreate(&e));
-  for (int i = 0; i < N; ++i) {
-    DADD_HIP(hipEventRecord(ev[2 * i], s));
-    DADD_HIP(hipEventRecord(ev[2 * i + 1], s));
-  }
-  DADD_HIP(hipEventSynchronize(ev[2 * N - 1]));
-  float t[N];
-  for (int i = 0; i < N; ++i) DADD_HIP(hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]));
-  for (auto& e : ev) (void)hipEventDestroy(e);
-  std::sort(t, t + N);
-  *out_ms = (double)t[N / 2];
+int dadd_prof_record(int i, const char** name, double out[3]) {
+  DADD_REQUIRE(!g_dadd_prof_on && i >= 0 && (size_t)i < g_prof.ms.size() && name && out,
+               "prof_record: index %d out of range (or profiling still active)", i);
+  *name = g_prof.rec[i].name;
+  out[0] = (double)g_prof.ms[i];
+  out[1] = g_prof.rec[i].flop;
+  out[2] = g_prof.rec[i].bytes;
   return DADD_OK;
 }
 

@@ -14,6 +14,8 @@
 //                     in registers for the whole block (they are step-invariant and tiny)
 #include <stdlib.h>
 
+#include <string>
+
 #include "dadd_common.h"
 #include "igemm_args.h"   // xcd_remap
 
@@ -510,7 +512,9 @@ int launch_flash(const FlashArgs& a, hipStream_t s) {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int smem = (PF ? 2 : 1) * (((D + 63) / 64) * 4096 + 64 * v_stride(DVP)) * (int)sizeof(half_t);
   dim3 grid(((a.N + 64 * QF - 1) / (64 * QF)) * a.B * a.H);
-  hipLaunchKernelGGL((flash_kernel<DR, QF, PF>), grid, dim3(256), smem, s, a);
+  static const std::string name = "flash_kernel<" + std::to_string(DR) + ", " + std::to_string(QF) + ", " + (PF ? "true" : "false") + ">";
+  const double tok = (double)a.B * a.N, c = (double)a.H * DR;
+  dadd_launch({name.c_str(), 4.0 * tok * a.N * c, tok * c * 2.0 * 4.0}, flash_kernel<DR, QF, PF>, grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
@@ -518,12 +522,16 @@ int launch_flash(const FlashArgs& a, hipStream_t s) {
 template <int DR>
 int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
   dim3 grid((a.N + 255) / 256, a.B * a.H);
+  static const std::string nm = "xattn_kernel<" + std::to_string(DR);
+  static const std::string n2t = nm + ", 2, true>", n3f = nm + ", 3, false>", n2f = nm + ", 2, false>";
+  const double tok = (double)a.B * a.N, c = (double)a.C;
+  const double bytes = tok * c * 4.0;
   if (mode == DADD_XATTN_BASELINE)
-    hipLaunchKernelGGL((xattn_kernel<DR, 2, true>), grid, dim3(256), 0, s, a);
+    dadd_launch({n2t.c_str(), 4.0 * tok * 32 * c, bytes}, xattn_kernel<DR, 2, true>, grid, dim3(256), 0, s, a);
   else if (a.lambda != 0.0f)
-    hipLaunchKernelGGL((xattn_kernel<DR, 3, false>), grid, dim3(256), 0, s, a);
+    dadd_launch({n3f.c_str(), 4.0 * tok * 48 * c, bytes}, xattn_kernel<DR, 3, false>, grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((xattn_kernel<DR, 2, false>), grid, dim3(256), 0, s, a);
+    dadd_launch({n2f.c_str(), 4.0 * tok * 32 * c, bytes}, xattn_kernel<DR, 2, false>, grid, dim3(256), 0, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

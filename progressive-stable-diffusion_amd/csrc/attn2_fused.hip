@@ -261,12 +261,15 @@ extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void*
   a.residual = static_cast<const half_t*>(residual);
   a.out = static_cast<half_t*>(out);
   a.B = B; a.HW = HW; a.C = C;
+  // algorithmic work: two GEMMs against the folded conditioning (K = C, N = 384 and K = 384, N = C)
+  const double flop = 4.0 * (double)B * HW * C * 384.0;
+  const double bytes = (double)B * HW * C * 2.0 * 3.0 + (double)B * 2.0 * 384.0 * C * 2.0;
   if (B * HW / 128 < g_attn2_cus)     // 128-token tiles would not fill the chip
-    hipLaunchKernelGGL(attn2_fused_kernel<64>, dim3(B * HW / 64), dim3(256), smem_bytes<64>(),
-                       static_cast<hipStream_t>(stream), a);
+    dadd_launch({"attn2_fused_kernel<64>", flop, bytes}, attn2_fused_kernel<64>, dim3(B * HW / 64), dim3(256),
+                smem_bytes<64>(), static_cast<hipStream_t>(stream), a);
   else
-    hipLaunchKernelGGL(attn2_fused_kernel<128>, dim3(B * HW / 128), dim3(256), smem_bytes<128>(),
-                       static_cast<hipStream_t>(stream), a);
+    dadd_launch({"attn2_fused_kernel<128>", flop, bytes}, attn2_fused_kernel<128>, dim3(B * HW / 128), dim3(256),
+                smem_bytes<128>(), static_cast<hipStream_t>(stream), a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

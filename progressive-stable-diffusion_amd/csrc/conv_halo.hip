@@ -345,9 +345,10 @@ int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "conv_halo: operand larger than the 2 GiB buffer window");
   dim3 grid(a.mtiles * a.ntiles, nsplit);
-  if (a.Wo == 64) hipLaunchKernelGGL(conv3x3_halo_kernel<64>, grid, dim3(512), SMEM_BYTES, s, a);
-  else if (a.Wo == 32) hipLaunchKernelGGL(conv3x3_halo_kernel<32>, grid, dim3(512), SMEM_BYTES, s, a);
-  else hipLaunchKernelGGL(conv3x3_halo_kernel<16>, grid, dim3(512), SMEM_BYTES, s, a);
+  const double flop = dadd_igemm_flop(a), bytes = dadd_igemm_bytes(a);
+  if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64>", flop, bytes}, conv3x3_halo_kernel<64>, grid, dim3(512), SMEM_BYTES, s, a);
+  else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32>", flop, bytes}, conv3x3_halo_kernel<32>, grid, dim3(512), SMEM_BYTES, s, a);
+  else dadd_launch({"conv3x3_halo_kernel<16>", flop, bytes}, conv3x3_halo_kernel<16>, grid, dim3(512), SMEM_BYTES, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels of libdadd_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -37,10 +38,29 @@ void dadd_set_error(const char* fmt, ...);
 
 static inline bool dadd_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// profiling hooks (api.hip)
-bool dadd_prof_active(int kind);
-void dadd_prof_pre(hipStream_t s);
-void dadd_prof_post(hipStream_t s, double flop);
+// ---- launch wrapper with per-kernel timing (api.hip) ------------------------------------------------------
+// Every kernel of the library is launched through dadd_launch().  While dadd_prof_begin() is active (eager
+// launches only, never during stream capture) the launch goes through hipExtLaunchKernelGGL with a start/stop
+// event pair: the pair carries the dispatch packet's OWN begin/end timestamps — the same clock rocprofv3's
+// kernel trace reads — so the per-launch time excludes queue gaps and event-record overhead.  `name` is the
+// rocprofv3 kernel name (without namespace / argument list), `flop` / `bytes` the launch's ALGORITHMIC work
+// (2*M*N*K; compulsory reads + writes) for the roofline columns.
+struct DaddLaunchTag {
+  const char* name;
+  double flop;
+  double bytes;
+};
+extern int g_dadd_prof_on;
+bool dadd_prof_slot(const DaddLaunchTag& tag, hipEvent_t* e0, hipEvent_t* e1);
+template <typename... KA, typename... A>
+inline void dadd_launch(const DaddLaunchTag& tag, void (*kernel)(KA...), dim3 grid, dim3 block, unsigned smem,
+                        hipStream_t s, A... args) {
+  hipEvent_t e0, e1;
+  if (g_dadd_prof_on && dadd_prof_slot(tag, &e0, &e1))
+    hipExtLaunchKernelGGL(kernel, grid, block, smem, s, e0, e1, 0, static_cast<KA>(args)...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, smem, s, static_cast<KA>(args)...);
+}
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float dadd_silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -228,7 +228,7 @@ extern "C" int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B,
   const size_t total = (size_t)B * H * W;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  dadd_launch({"pack_kernel", 0.0, (double)total * (C * 4.0 + 16.0)}, pack_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      static_cast<half_t*>(out), B, C, H * W, scale, mat, vec);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
@@ -241,7 +241,7 @@ extern "C" int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* 
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(w) && dadd_aligned16(out),
                "conv_cin8: pointers must be 16-byte aligned");
   const int npix = B * H * W;
-  hipLaunchKernelGGL(conv_cin8_kernel, dim3((npix + 255) / 256, Cout / 8), dim3(256), 0,
+  dadd_launch({"conv_cin8_kernel", 2.0 * npix * Cout * 72.0, (double)npix * (16.0 + 2.0 * Cout)}, conv_cin8_kernel, dim3((npix + 255) / 256, Cout / 8), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), bias, static_cast<half_t*>(out), B, H, W, Cout);
   DADD_LAUNCH_CHECK();
@@ -255,7 +255,7 @@ extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float*
                "conv_cout4: C must be x8 and Cout in 1..4");
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(w), "conv_cout4: pointers must be 16-byte aligned");
   const int npix = B * H * W;
-  hipLaunchKernelGGL(conv_cout4_kernel, dim3((npix + 15) / 16), dim3(256), 0,
+  dadd_launch({"conv_cout4_kernel", 2.0 * npix * Cout * 9.0 * C, (double)npix * (2.0 * C + 4.0 * Cout)}, conv_cout4_kernel, dim3((npix + 15) / 16), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const half_t*>(x),
                      static_cast<const half_t*>(w), bias, out_nchw, B, H, W, C, Cout, mode);
   DADD_LAUNCH_CHECK();
@@ -265,7 +265,7 @@ extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float*
 extern "C" int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream) {
   DADD_REQUIRE(t && out && M > 0 && dim > 0 && dim % 2 == 0, "timestep_features: bad arguments");
   const int n = M * dim / 2;
-  hipLaunchKernelGGL(timestep_features_kernel, dim3((n + 255) / 256), dim3(256), 0,
+  dadd_launch({"timestep_features_kernel", 0.0, (double)M * dim * 4.0}, timestep_features_kernel, dim3((n + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), t, out, M, dim);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
@@ -276,7 +276,7 @@ extern "C" int dadd_linear_rows_f32(const float* x, const void* w, const float* 
   DADD_REQUIRE(x && w && out, "linear_rows: null pointer");
   DADD_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && K <= 2048, "linear_rows: K must be x8, <=2048");
   DADD_REQUIRE(dadd_aligned16(w), "linear_rows: w must be 16-byte aligned");
-  hipLaunchKernelGGL(linear_rows_kernel, dim3((N + 3) / 4), dim3(256), (size_t)8 * K * sizeof(float),
+  dadd_launch({"linear_rows_kernel", 2.0 * M * N * K, 2.0 * N * K + 4.0 * M * (K + N)}, linear_rows_kernel, dim3((N + 3) / 4), dim3(256), (unsigned)(8 * K * sizeof(float)),
                      static_cast<hipStream_t>(stream), x, static_cast<const half_t*>(w), bias, out, M,
                      K, N, act_in, act_out);
   DADD_LAUNCH_CHECK();
@@ -287,7 +287,7 @@ extern "C" int dadd_begin_step(const float* table, float* cur_rows, int B, int n
                                float* cur_coef, int32_t* step, void* stream) {
   DADD_REQUIRE(table && cur_rows && coef && cur_coef && step && B > 0 && ncols > 0,
                "begin_step: bad arguments");
-  hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+  dadd_launch({"begin_step_kernel", 0.0, 4.0 * ncols * (1.0 + B)}, begin_step_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      table, cur_rows, B, ncols, coef, cur_coef, step);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
@@ -298,7 +298,7 @@ extern "C" int dadd_ddim_update_f32(float* x, const float* eps_c, const float* e
   DADD_REQUIRE(x && eps_c && coef && n > 0, "ddim_update: bad arguments");
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(ddim_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+  dadd_launch({"ddim_kernel", 0.0, (double)n * (eps_u ? 16.0 : 12.0)}, ddim_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      eps_c, eps_u, guidance, coef, n);
   DADD_LAUNCH_CHECK();
   return DADD_OK;

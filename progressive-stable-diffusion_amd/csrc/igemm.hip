@@ -16,6 +16,7 @@
 #include "dadd_common.h"
 #include "igemm_args.h"
 #include <cstdlib>
+#include <string>
 #include "igemm_epilogue.h"
 
 namespace {
@@ -236,7 +237,8 @@ int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
   const int mtiles = (a.M + BM - 1) / BM;
   dim3 grid(mtiles * a.ntiles, nsplit);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, DEEP>), grid, dim3(256), smem, s, a);
+  static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + (DEEP ? "true" : "false") + ">";
+  dadd_launch({name.c_str(), dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_kernel<BM, BN, DEEP>, grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
@@ -368,13 +370,6 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     a.splitk = halo_ns;
     DADD_REQUIRE(halo_ns == 1 || a.partial != nullptr, "igemm: split-K needs a partial buffer");
   }
-  // profiling family 1 = every implicit GEMM / conv; family 2 = exactly igemm_dma_kernel<160, false, false, true>
-  // (the kernel with the largest share of GPU time: one row of a rocprofv3 --stats summary); family 3 = exactly
-  // conv3x3_halo_kernel<64>
-  const bool prof = dadd_prof_active(1) ||
-                    (dadd_prof_active(2) && !halo && dma && tile_n == 160 && !a.ups && !dadd_igemm_dma_persistent(a, nsplit)) ||
-                    (dadd_prof_active(3) && halo && a.Wo == 64);
-  if (prof) dadd_prof_pre(s);
   if (halo)
     rc = dadd_launch_conv_halo(a, halo_ns, s);
   else if (dma)
@@ -383,13 +378,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     rc = (tile_n == 160) ? launch<128, 160, false>(a, nsplit, s) : launch2<128, 128>(a, nsplit, deep, s);
   else
     rc = (tile_n == 160) ? launch2<64, 160>(a, nsplit, deep, s) : launch2<64, 128>(a, nsplit, deep, s);
-  if (prof) dadd_prof_post(s, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (rc != DADD_OK) return rc;
   if ((halo ? halo_ns : nsplit) > 1 && a.counters == nullptr) {
     const size_t total = (size_t)a.M * (a.N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, halo ? halo_ns : nsplit);
+    const int ns = halo ? halo_ns : nsplit;
+    dadd_launch({"splitk_finish_kernel", 0.0, (double)a.M * a.N * (4.0 * ns + 2.0 + ((a.flags & DADD_EPI_RESIDUAL) ? 2.0 : 0.0))},
+                splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, ns);
     DADD_LAUNCH_CHECK();
   }
   return DADD_OK;

@@ -59,6 +59,14 @@ __device__ __forceinline__ void tile_decode(const IgemmArgs& p, int tile_id, int
   }
 }
 
+// algorithmic work of one implicit-GEMM launch (roofline columns of the profiling records)
+static inline double dadd_igemm_flop(const IgemmArgs& a) { return 2.0 * (double)a.M * (double)a.N * (double)a.K; }
+static inline double dadd_igemm_bytes(const IgemmArgs& a) {
+  const double n_out = (a.flags & DADD_EPI_GEGLU) ? a.N / 2 : a.N;
+  return 2.0 * ((double)a.B * a.Hi * a.Wi * (a.C1 + a.C2) + (double)a.N * a.K + (double)a.M * n_out +
+                ((a.flags & DADD_EPI_RESIDUAL) ? (double)a.M * a.N : 0.0));
+}
+
 int dadd_init_igemm_dma();
 int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s);
 bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit);

@@ -467,11 +467,7 @@ int g_num_cu = 0;
 }  // namespace
 
 int dadd_init_igemm_dma() {
-  int rc = set_attr<128, false, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, true, false, false>();
-  if (rc == DADD_OK) rc = set_attr<160, false, false, false>();
-  if (rc == DADD_OK) rc = set_attr<160, true, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, false, true, true>();
+  int rc = set_attr<128, false, true, true>();
   if (rc == DADD_OK) rc = set_attr<160, false, true, true>();
   if (rc == DADD_OK) rc = set_attr<128, false, false, true>();
   if (rc == DADD_OK) rc = set_attr<128, true, false, true>();
@@ -498,29 +494,21 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "igemm(dma): operand larger than the 2 GiB buffer window");
   constexpr int smem160 = smem_bytes<160>(), smem128 = smem_bytes<128>();
+  const double flop = dadd_igemm_flop(a), bytes = dadd_igemm_bytes(a);
   if (dadd_igemm_dma_persistent(a, nsplit)) {
     dim3 grid(g_num_cu);
-    if (tile_n == 160) hipLaunchKernelGGL((igemm_dma_kernel<160, false, true, true>), grid, dim3(512), smem160, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, true, true>), grid, dim3(512), smem128, s, a);
+    if (tile_n == 160) dadd_launch({"igemm_dma_kernel<160, false, true, true>", flop, bytes}, igemm_dma_kernel<160, false, true, true>, grid, dim3(512), smem160, s, a);
+    else dadd_launch({"igemm_dma_kernel<128, false, true, true>", flop, bytes}, igemm_dma_kernel<128, false, true, true>, grid, dim3(512), smem128, s, a);
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }
   dim3 grid(total, nsplit);
-  static const bool no_ws = getenv("DADD_NO_WS") != nullptr;   // A/B measurements only
-  if (!no_ws) {
-    if (tile_n == 160) {
-      if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true, false, true>), grid, dim3(512), smem160, s, a);
-      else hipLaunchKernelGGL((igemm_dma_kernel<160, false, false, true>), grid, dim3(512), smem160, s, a);
-    } else {
-      if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true, false, true>), grid, dim3(512), smem128, s, a);
-      else hipLaunchKernelGGL((igemm_dma_kernel<128, false, false, true>), grid, dim3(512), smem128, s, a);
-    }
-  } else if (tile_n == 160) {
-    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<160, true, false, false>), grid, dim3(256), smem160, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<160, false, false, false>), grid, dim3(256), smem160, s, a);
+  if (tile_n == 160) {
+    if (a.ups) dadd_launch({"igemm_dma_kernel<160, true, false, true>", flop, bytes}, igemm_dma_kernel<160, true, false, true>, grid, dim3(512), smem160, s, a);
+    else dadd_launch({"igemm_dma_kernel<160, false, false, true>", flop, bytes}, igemm_dma_kernel<160, false, false, true>, grid, dim3(512), smem160, s, a);
   } else {
-    if (a.ups) hipLaunchKernelGGL((igemm_dma_kernel<128, true, false, false>), grid, dim3(256), smem128, s, a);
-    else hipLaunchKernelGGL((igemm_dma_kernel<128, false, false, false>), grid, dim3(256), smem128, s, a);
+    if (a.ups) dadd_launch({"igemm_dma_kernel<128, true, false, true>", flop, bytes}, igemm_dma_kernel<128, true, false, true>, grid, dim3(512), smem128, s, a);
+    else dadd_launch({"igemm_dma_kernel<128, false, false, true>", flop, bytes}, igemm_dma_kernel<128, false, false, true>, grid, dim3(512), smem128, s, a);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

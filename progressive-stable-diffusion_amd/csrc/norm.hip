@@ -404,21 +404,22 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t slab_bytes = (size_t)HW * p.cg * sizeof(half_t);
+  const double act_bytes = (double)B * HW * C * 2.0;
   if (slab_bytes <= (size_t)GN_FUSED_MAX_BYTES && p.cg % 2 == 0 && C1 % 2 == 0) {
-    hipLaunchKernelGGL(gn_fused_kernel, dim3(groups, B), dim3(256), slab_bytes, s, p);
+    dadd_launch({"gn_fused_kernel", 0.0, act_bytes * 2.0}, gn_fused_kernel, dim3(groups, B), dim3(256), (unsigned)slab_bytes, s, p);
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }
   const size_t sm1 = (size_t)2 * p.RP * C * sizeof(float);
   const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.nchunk, B), dim3(256), sm1, s, p);
+  dadd_launch({"gn_stats_kernel", 0.0, act_bytes}, gn_stats_kernel, dim3(p.nchunk, B), dim3(256), (unsigned)sm1, s, p);
   DADD_LAUNCH_CHECK();
   if (fin_in_apply) {
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nrb, B), dim3(256), sm2, s, p);
+    dadd_launch({"gn_apply_kernel<true>", 0.0, act_bytes * 2.0}, gn_apply_kernel<true>, dim3(nrb, B), dim3(256), (unsigned)sm2, s, p);
   } else {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
+    dadd_launch({"gn_finalize_kernel", 0.0, (double)B * p.nchunk * groups * 8.0}, gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
     DADD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nrb, B), dim3(256), sm2, s, p);
+    dadd_launch({"gn_apply_kernel<false>", 0.0, act_bytes * 2.0}, gn_apply_kernel<false>, dim3(nrb, B), dim3(256), (unsigned)sm2, s, p);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;
@@ -431,9 +432,9 @@ extern "C" int dadd_layernorm_f16(const void* x, const float* gamma, const float
                "layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXV);
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(out) && dadd_aligned16(gamma) &&
                    dadd_aligned16(beta), "layernorm: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), gamma, beta,
-                     static_cast<half_t*>(out), M, C, eps);
+  dadd_launch({"layernorm_kernel", 0.0, (double)M * C * 4.0}, layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0,
+              static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), gamma, beta,
+              static_cast<half_t*>(out), M, C, eps);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

@@ -59,9 +59,9 @@ PROTOTYPES = {
     "dadd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "dadd_graph_launch": (C.c_int, [vp, vp]),
     "dadd_graph_destroy": (C.c_int, [vp]),
-    "dadd_prof_begin": (C.c_int, [C.c_int]),
-    "dadd_prof_end": (C.c_int, [C.POINTER(C.c_double)]),
-    "dadd_prof_event_overhead": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dadd_prof_begin": (C.c_int, []),
+    "dadd_prof_end": (C.c_int, [C.POINTER(C.c_int)]),
+    "dadd_prof_record": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None

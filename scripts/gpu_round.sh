@@ -2,7 +2,7 @@
 # One gpurun call = one box acquisition (minutes of budget): run the whole GPU checklist in it.
 # A step that TIMES OUT or is KILLED ends the call (no further GPU work on a possibly wedged card);
 # ordinary test failures are logged and the later steps still run.
-# usage: scripts/gpu_round.sh <tag> [steps...]   steps: kernels parity smoke bench prof pmc
+# usage: scripts/gpu_round.sh <tag> [steps...]   steps: kernels parity smoke stepprof stepprofvae bench prof pmc
 set -u
 tag=${1:-r01}; shift || true
 steps=${*:-"kernels parity smoke bench prof"}
@@ -23,6 +23,8 @@ for s in $steps; do
     kernels) run kernels 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=300 ;;
     parity)  run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 ;;
     smoke)   run smoke 300 python __graft_entry__.py smoke ;;
+    stepprof) TAILN=60 run stepprof 600 python scripts/step_profile.py --list --out "$out/step_profile.txt" ;;
+    stepprofvae) TAILN=40 run stepprofvae 600 python scripts/step_profile.py --vae --list --out "$out/step_profile_vae.txt" ;;
     opbench) TAILN=80 run opbench 600 python scripts/op_bench.py "$tag" ;;
     opbenchvae) TAILN=60 run opbenchvae 600 python scripts/op_bench.py "$tag" --vae ;;
     bench)   run bench 900 python bench.py --steps 2 --warmup 1 ;;

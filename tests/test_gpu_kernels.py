@@ -417,11 +417,28 @@ def test_begin_step_and_graph_replay(hip):
 
 
 def test_profiling_hooks(hip):
+    """Every launch between prof_begin / prof_end is recorded with its kernel name, its own begin/end
+    timestamps and its algorithmic flop / bytes; capture is refused while profiling."""
     x, w = rnd((1, 256, 1, 320), 50), rnd((320, 320), 51, 0.05)
     xd, wd, o = dev(hip, x), dev(hip, w), hip.zeros((1, 256, 1, 320), F16)
-    hip.prof_begin(1)
+    ln = hip.zeros((1, 256, 1, 320), F16)
+    g, b = dev(hip, torch.ones(320)), dev(hip, torch.zeros(320))
+    hip.igemm(xd, wd, o)
+    hip.synchronize()
+    hip.prof_begin()
     for _ in range(3):
         hip.igemm(xd, wd, o)
-    st = hip.prof_end()
-    assert st["launches"] == 3 and st["ms"] > 0
-    assert st["flop"] == pytest.approx(3 * 2.0 * 256 * 320 * 320)
+        hip.layernorm(o, g, b, ln)
+    with pytest.raises(ValueError):
+        hip.graph_begin()
+    rec = hip.prof_end()
+    assert len(rec) == 6 and [r[0].split("<")[0] for r in rec[:2]] == [rec[0][0].split("<")[0], "layernorm_kernel"]
+    assert "igemm" in rec[0][0]
+    for name, us, flop, byt in rec:
+        assert 0.5 < us < 500.0, (name, us)
+        if "igemm" in name:
+            assert flop == pytest.approx(2.0 * 256 * 320 * 320) and byt == pytest.approx(2.0 * (2 * 256 * 320 + 320 * 320))
+        else:
+            assert flop == 0.0 and byt == pytest.approx(256 * 320 * 4.0)
+    hip.igemm(xd, wd, o)          # not recorded any more
+    assert hip.prof_end.__self__ is hip

@@ -22,7 +22,7 @@ from tests import golden_inputs as GI
 pytestmark = pytest.mark.gpu
 F16, F32 = torch.float16, torch.float32
 DEV = torch.device("cuda:0")
-TINY_CLIP = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+TINY_CLIP = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1,
                  image_size=224, patch_size=14, projection_dim=32)
 
 
@@ -277,3 +277,204 @@ def test_full_size_properties(full_sd):
     with torch.no_grad():
         img = PIPE._latents_to_images(mod, z3)
     assert img.shape == (4, 3, 512, 512) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 2: the evidence VERDICT r1 asked for — golden conditioning through the PRODUCT classes on the device,
+# BASELINE config 3's workload on one GPU (B = 13 plan == four padded shards), full-size kernels vs the oracle.
+def test_golden_conditioning_through_product_classes(golden_dir):
+    """tests/golden/conditioning.npz = outputs of the imported reference classes (oracle/make_golden.py).  Here the
+    product's ``conditioning.py`` classes produce them on the device: fp32 tolerance 2e-5 (+1e-5 relative)."""
+    from progressive_stable_diffusion_amd import conditioning as PC
+    from progressive_stable_diffusion_amd import weights as W
+    g = np.load(os.path.join(golden_dir, "conditioning.npz"))
+    sd = W.init_state_dict(W.conditioning_shapes(), GI.SEED)
+
+    def close(got, key):
+        ref = torch.from_numpy(g[key])
+        err = (got.float().cpu() - ref).abs()
+        assert got.shape == ref.shape and bool((err <= 2e-5 + 1e-5 * ref.abs()).all()), (key, err.max().item())
+
+    aoe = PC.AdditiveOrdinalEmbedder(sd, DEV)
+    labels, source = torch.tensor(GI.LABELS, device=DEV), torch.tensor(GI.SOURCE, device=DEV)
+    close(aoe(labels), "aoe_forward")
+    close(aoe.get_negative_embedding(labels), "aoe_negative")
+    close(aoe.get_ordinal_delta_embedding(source, labels), "aoe_delta")
+    assert aoe.get_ordinal_delta_embedding(labels, labels).abs().max().item() == 0.0     # ordinal_embedder.py:254-255
+    pur = PC.FeaturePurifier(sd, DEV)
+    close(pur(GI.purifier_image_tokens().to(DEV), aoe(torch.tensor(GI.PUR_SOURCE, device=DEV))), "pur_out")
+    close(PC.ImageProjectionPlus(sd, DEV)(GI.clip_hidden().to(DEV)), "plus_out")
+    sd_b = W.init_state_dict(W.conditioning_shapes(projection_plus=False, purifier=False), GI.SEED)
+    close(PC.ImageProjection(sd_b, DEV)(GI.clip_embeds().to(DEV)), "basic_out")
+
+
+def test_config3_sweep_single_plan_and_four_shards(full_sd):
+    """BASELINE config 3 on one GPU: the 13-label MES sweep ``linspace(0, 3, 13)``, source 0, ONE shared
+    CPU-seeded latent — (i) as the single B = 13 plan the reference ``main()`` builds
+    (inference_pipeline_ip.py:604-612,646-661) vs the oracle at 256x256 / 10 steps (labels 0, 0.25, 1.5, 2.75, 3); (ii) as four padded shards of
+    4 through ``distributed.shard_labels`` (what 4 ranks would run) whose concatenation, padding dropped, matches
+    the B = 13 result.  Tolerances: latents 5e-2 vs the oracle (fp16 storage), 2e-2 between the two HIP plans
+    (same arithmetic, other tilings / split-K orders); frames 3e-2 max."""
+    from progressive_stable_diffusion_amd import distributed as D
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 256, 13)
+    labels = PIPE._build_labels(13, 0.0, 3.0)
+    assert labels[1].item() == 0.25 and labels[-1].item() == 3.0
+    pix = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    lat1 = D.shared_initial_latent(1234, 4, 32)
+    with torch.no_grad():
+        z13 = PIPE._ddim_sample_ip(mod, labels.to(DEV), torch.zeros(13, device=DEV), pix.to(DEV), 10, DEV,
+                                   steer_scale=3.0, latents=lat1.repeat(13, 1, 1, 1))
+        img13 = PIPE._latents_to_images(mod, z13)
+        feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
+        # the oracle is per-sample independent (as is the reference): five of the 13 labels keep its CPU time ~1 min
+        sub = torch.tensor([0, 1, 6, 11, 12])
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        z_ref = OS.ddim_sample(full_sd, _ocfg(mod), labels[sub], torch.zeros(5), feats, 10, lat1.repeat(5, 1, 1, 1),
+                               steer_scale=3.0)
+        shards, frames = [], []
+        for rank in range(4):
+            loc, n_valid = D.shard_labels(labels, rank, 4, 4)
+            assert loc.shape[0] == 4 and n_valid == (4 if rank < 3 else 1)
+            z = PIPE._ddim_sample_ip(mod, loc.to(DEV), torch.zeros(4, device=DEV), pix.to(DEV), 10, DEV,
+                                     steer_scale=3.0, latents=lat1.repeat(4, 1, 1, 1))
+            shards.append(z)
+            frames.append(PIPE._latents_to_images(mod, z))
+    z16, img16 = torch.cat(shards), torch.cat(frames)
+    assert torch.equal(z16[12], z16[13]) and torch.equal(z16[13], z16[15])          # padding repeats the last label
+    e_oracle = (z13.cpu()[sub] - z_ref).abs().max().item()
+    e_shard = (z16[:13] - z13).abs().max().item()
+    e_img = (img16[:13] - img13).abs().max().item()
+    print(f"config3 sweep: B=13 vs oracle {e_oracle:.3e}; 4x4 shards vs B=13 latents {e_shard:.3e} frames {e_img:.3e}")
+    assert e_oracle < 5e-2 and e_shard < 2e-2 and e_img < 3e-2
+    # label 0 == source 0: its delta tokens are exactly zero, lambda cannot act on it (SURVEY.md App. E.3)
+    with torch.no_grad():
+        z0 = PIPE._ddim_sample_ip(mod, labels.to(DEV), torch.zeros(13, device=DEV), pix.to(DEV), 10, DEV,
+                                  steer_scale=0.0, latents=lat1.repeat(13, 1, 1, 1))
+    assert (z0[0] - z13[0]).abs().max().item() < 1e-5 and (z13[12] - z13[0]).abs().max().item() > 1e-3
+
+
+def test_config3_sweep_full_size_properties(full_sd):
+    """The same sweep at BASELINE size (512x512, 50 steps) as the single B = 13 plan: properties only."""
+    from progressive_stable_diffusion_amd import distributed as D
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 512, 13)
+    labels = PIPE._build_labels(13, 0.0, 3.0).to(DEV)
+    pix = (torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    lat = D.shared_initial_latent(1234, 4, 64).repeat(13, 1, 1, 1)
+    with torch.no_grad():
+        z = PIPE._ddim_sample_ip(mod, labels, torch.zeros(13, device=DEV), pix, 50, DEV, steer_scale=3.0, latents=lat)
+        z_again = PIPE._ddim_sample_ip(mod, labels, torch.zeros(13, device=DEV), pix, 50, DEV, steer_scale=3.0, latents=lat)
+        z_l0 = PIPE._ddim_sample_ip(mod, labels, torch.zeros(13, device=DEV), pix, 50, DEV, steer_scale=0.0, latents=lat)
+        img = PIPE._latents_to_images(mod, z)
+    assert torch.isfinite(z).all() and float(z.abs().max()) <= 4.0 + 1e-6 and torch.equal(z, z_again)
+    assert (z_l0 - z_l0[:1]).abs().max().item() < 1e-5            # lambda = 0: every label yields the same image
+    assert (z[0] - z_l0[0]).abs().max().item() < 1e-5             # target == source: steering is a no-op
+    d = [(z[i + 1] - z[i]).abs().mean().item() for i in range(12)]
+    assert min(d) > 0.0                                           # every step of the progression moves the image
+    assert img.shape == (13, 3, 512, 512) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
+def test_vae_decode_512_matches_oracle(hip, full_sd):
+    """VAE decode at BASELINE size (64x64 latent -> 512x512, B = 1) vs the oracle: the 512x512 / 256x256 kernels
+    (128-channel register-staged convs, upsample gathers) get parity, not only a range check."""
+    from progressive_stable_diffusion_amd.engine import VaeDecoderPlan
+    plan = VaeDecoderPlan(hip, full_sd, 1, 64, latent_scale=0.18215)
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(8)) * 0.18215 * 1.5
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref = ((vae_decode(full_sd, z / 0.18215).clamp(-1, 1) + 1) / 2).clamp(0, 1)
+    hip.copy_(plan.z_in, z.to(DEV))
+    plan.run()
+    hip.synchronize()
+    d = (plan.img_out.cpu() - ref).abs()
+    print(f"vae decode 512: max {d.max():.3e} mean {d.mean():.3e}")
+    assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
+
+
+def test_unet_call_512_matches_oracle(hip, full_sd):
+    """One eps call at BASELINE size (64x64 latent, B = 1, lambda = 3): the 64x64-level kernels (halo conv W = 64,
+    flash d = 40 at 4096 keys, the fused attn2 when eligible) against the oracle."""
+    from progressive_stable_diffusion_amd.engine import UNetPlan
+    plan = UNetPlan(hip, full_sd, 1, 64)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1, 4, 64, 64, generator=g)
+    cond = torch.randn(1, 48, 768, generator=g) * 0.5
+    t = torch.tensor([650])
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref = unet_forward(full_sd, x, t, cond, delta_scale=3.0)
+    got = plan.forward(x.to(DEV), t.to(DEV), cond.to(DEV), lam=3.0)
+    hip.synchronize()
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"unet 512 call: max err {err:.3e} (max |eps| {ref.abs().max():.3f})")
+    assert err < 1e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_stochastic_sampler_on_device(full_sd):
+    """eta > 0 (inference_pipeline_ip.py:457-468) through the HIP engine with injected per-step noise vs the oracle."""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 128, 2)
+    target, source = torch.tensor([3.0, 0.5]), torch.tensor([1.0, 2.0])
+    pix = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(9))
+    noise = torch.randn(3, 2, 4, 16, 16, generator=torch.Generator().manual_seed(10))
+    with torch.no_grad():
+        z = PIPE._ddim_sample_ip(mod, target.to(DEV), source.to(DEV), pix.to(DEV), 4, DEV, eta=0.5, steer_scale=2.0,
+                                 latents=lat, step_noise=noise)
+        feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
+        z_ref = OS.ddim_sample(full_sd, _ocfg(mod), target, source, feats, 4, lat, eta=0.5, steer_scale=2.0,
+                               step_noise=noise)
+    assert (z.cpu() - z_ref).abs().max().item() < 5e-2
+
+
+def test_module_cond_cache_on_device(full_sd):
+    """ADVICE r1 (high) on the real backend: a sampler run between two module() calls must not leave stale K/V."""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 64, 2, clip_config=TINY_CLIP)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 8, 8, generator=g).to(DEV)
+    t = torch.tensor([500, 20], device=DEV)
+    cA = (torch.randn(2, 48, 768, generator=g) * 0.5).to(DEV)
+    PIPE._set_delta_scale_on_processors(mod, 1.5)
+    with torch.no_grad():
+        eA = mod(x, t, cA).clone()
+        pix = torch.rand(1, 3, 224, 224, generator=g).to(DEV)
+        PIPE._ddim_sample_ip(mod, torch.tensor([3.0, 1.0], device=DEV), torch.zeros(2, device=DEV), pix, 2, DEV,
+                             steer_scale=1.5)
+        assert torch.equal(mod(x, t, cA), eA)
+        assert torch.equal(mod(x, torch.tensor(500), cA)[0], mod(x, torch.tensor([500, 500], device=DEV), cA)[0])
+
+
+def test_main_cli_end_to_end(full_sd, tmp_path):
+    """``main()`` as the reference CLI runs it (inference_pipeline_ip.py:566-669): YAML config + tensors-only
+    checkpoint (tiny CLIP tower inside, geometry read from its tensors) + structure image -> PNG sequence + grid."""
+    import numpy as np
+    import yaml
+    from PIL import Image
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    from progressive_stable_diffusion_amd import weights as W
+    from progressive_stable_diffusion_amd.conditioning import ImageEncoder
+    from progressive_stable_diffusion_amd.config import default_config
+    shapes = dict(W.unet_shapes())
+    shapes.update(W.vae_shapes(encoder=False))
+    shapes.update(W.conditioning_shapes(clip_hidden=TINY_CLIP["hidden_size"], clip_proj=TINY_CLIP["projection_dim"]))
+    sd = W.init_state_dict(shapes, 0, gates=GI.GATES)
+    enc = ImageEncoder("cpu", seed=3, clip_config=TINY_CLIP)
+    sd.update({"image_encoder.image_encoder." + k: v for k, v in enc.image_encoder.state_dict().items()})
+    torch.save({"state_dict": sd}, tmp_path / "last.ckpt")
+
+    def plain(o):
+        return {k: plain(v) for k, v in o.items()} if isinstance(o, dict) else ([plain(v) for v in o] if isinstance(o, list) else o)
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump(plain(default_config(**{"dataset.image_size": 64}))))
+    Image.fromarray((np.random.RandomState(0).rand(70, 90, 3) * 255).astype("uint8")).save(tmp_path / "s.png")
+    out = tmp_path / "out"
+    PIPE.main(["--checkpoint", str(tmp_path / "last.ckpt"), "--config", str(tmp_path / "cfg.yaml"),
+               "--structure-image", str(tmp_path / "s.png"), "--output-dir", str(out), "--mes-steps", "3",
+               "--sampling-steps", "2", "--steer-scale", "2.0", "--seed", "7", "--device", "cuda"])
+    names = sorted(os.listdir(out))
+    assert names == ["mes_0.00_00.png", "mes_1.50_01.png", "mes_3.00_02.png", "progression_grid.png",
+                     "structure_reference.png"]
+    a = np.asarray(Image.open(out / "mes_0.00_00.png"))
+    b = np.asarray(Image.open(out / "mes_3.00_02.png"))
+    assert a.shape == (64, 64, 3) and np.abs(a.astype(int) - b.astype(int)).max() > 0
