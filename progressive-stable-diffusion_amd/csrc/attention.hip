@@ -565,7 +565,7 @@ extern "C" int dadd_self_attn_f16(const void* q, const void* k, const void* v, v
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d) {
     case 40:   // 64 queries per wave once the grid still fills the chip (>= 2 blocks per CU)
-      return ((long)B * heads * ((N + 255) / 256) >= 512 && !getenv("DADD_FLASH_QF2"))
+      return ((long)B * heads * ((N + 255) / 256) >= 512)
                  ? launch_flash<40, 4, true>(a, s) : launch_flash<40, 2, true>(a, s);
     case 80: return launch_flash<80, 2, true>(a, s);
     case 160: return launch_flash<160, 2, true>(a, s);

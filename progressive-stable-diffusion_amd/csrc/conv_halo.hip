@@ -332,8 +332,7 @@ int dadd_init_conv_halo() {
 
 // Shapes this kernel takes (everything else stays on the implicit GEMM).
 bool dadd_conv_halo_applicable(const IgemmArgs& a, int tile_n) {
-  static const bool off = getenv("DADD_NO_HALO") != nullptr;   // A/B measurements only
-  return !off && a.taps == 9 && a.stride == 1 && a.pad == 1 && !a.ups && tile_n == BN &&
+  return a.taps == 9 && a.stride == 1 && a.pad == 1 && !a.ups && tile_n == BN &&
          a.Hi == a.Ho && a.Wi == a.Wo && (a.Wo == 16 || a.Wo == 32 || a.Wo == 64) &&
          (a.Ho * a.Wo) % BM == 0 && (BM / a.Wo + 2) * (a.Wo + 2) <= HALO_MAX_PIX &&
          !(a.flags & (DADD_EPI_GEGLU | DADD_TUNE_PERSIST));

@@ -314,7 +314,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     tile_n = 128;
   }
   if (tile_n == 0) tile_n = (a.N % 160 == 0) ? 160 : 128;
-  DADD_REQUIRE(tile_n == 128 || tile_n == 160, "igemm: tile_n must be 128 or 160");
+  DADD_REQUIRE(tile_n == 64 || tile_n == 128 || tile_n == 160, "igemm: tile_n must be 64, 128 or 160");
   a.ntiles = (a.N + tile_n - 1) / tile_n;
 
   int splitk = d->splitk > 1 ? d->splitk : 1;
@@ -333,11 +333,8 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // tile order (igemm_args.h tile_decode): split the larger operand across the XCDs' L2s
   a.mtiles = (a.M + tile_m - 1) / tile_m;
   {
-    static const bool legacy = getenv("DADD_TILE_ORDER_LEGACY") != nullptr;   // A/B measurements only
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * Cin, w_bytes = 2.0 * a.N * a.K;
-    if (legacy) {
-      a.gm = a.gn = 0;
-    } else if (a_bytes >= w_bytes) {
+    if (a_bytes >= w_bytes) {
       a.gm = (a.mtiles + 7) / 8;
       a.gn = a.ntiles;
     } else {
@@ -345,21 +342,21 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
       a.gn = (a.ntiles + 7) / 8;
     }
   }
-  {
-    static const int korder_env = getenv("DADD_K_ORDER") ? atoi(getenv("DADD_K_ORDER")) : -1;   // A/B only
-    // taps-fastest order measured no different from channels-fastest (the DMA stream is bound by its
-    // instruction issue rate, not by L2->L1 bytes: profiles/r01_x_dma_limits.txt) -> opt-in only
-    a.korder = (a.taps == 9 && korder_env > 0) ? 1 : 0;
-  }
+  // K order of the LDS-DMA kernel: channels fastest.  (Taps fastest — the nine taps of a 64-channel chunk as
+  // consecutive K tiles — measured no different: the DMA stream is bound by the L2->LDS fill rate of a CU, not by
+  // L1 hits: profiles/r01_x_dma_limits.txt.)
+  a.korder = 0;
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
-  const bool dma = tile_m == 128 && (d->flags & DADD_TUNE_NODMA) == 0;
+  const bool dma = (d->flags & DADD_TUNE_NODMA) == 0;
+  DADD_REQUIRE(tile_n != 64 || (dma && tile_m == 64 && !geglu), "igemm: 64-column tiles exist for the 64-row LDS-DMA kernel only");
+  DADD_REQUIRE(!(dma && tile_m == 64 && a.ups), "igemm: the 64-row LDS-DMA tiles have no upsample gather");
   // persistent ring: a workgroup walks a contiguous run of tiles; with the column tile fastest the run
   // keeps ONE activation row tile (L2-hot after the first tile) and streams the weight tiles
-  if (dma && dadd_igemm_dma_persistent(a, nsplit)) a.gm = a.gn = 0;
+  if (dma && tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit)) a.gm = a.gn = 0;
   // 3x3 / stride 1 on whole-row tiles: the halo-resident kernel (conv_halo.hip); K slices = channel chunks
-  const bool halo = dma && dadd_conv_halo_applicable(a, tile_n);
+  const bool halo = dma && tile_m == 128 && dadd_conv_halo_applicable(a, tile_n);
   int halo_ns = 1;
   if (halo) {
     const int chunks = Cin / BK;
@@ -373,7 +370,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   if (halo)
     rc = dadd_launch_conv_halo(a, halo_ns, s);
   else if (dma)
-    rc = dadd_launch_igemm_dma(a, tile_n, nsplit, s);
+    rc = dadd_launch_igemm_dma(a, tile_m, tile_n, nsplit, s);
   else if (tile_m == 128)
     rc = (tile_n == 160) ? launch<128, 160, false>(a, nsplit, s) : launch2<128, 128>(a, nsplit, deep, s);
   else

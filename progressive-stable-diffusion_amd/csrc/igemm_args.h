@@ -68,7 +68,7 @@ static inline double dadd_igemm_bytes(const IgemmArgs& a) {
 }
 
 int dadd_init_igemm_dma();
-int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s);
+int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_m, int tile_n, int nsplit, hipStream_t s);
 bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit);
 int dadd_init_conv_halo();
 bool dadd_conv_halo_applicable(const IgemmArgs& a, int tile_n);

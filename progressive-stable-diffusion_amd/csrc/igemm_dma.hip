@@ -22,16 +22,7 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
-
-// Diagnostic builds only (scripts/exp_dma_limits.sh; the product library is built without the macro):
-// 1 = DMA stream without the MFMAs, 2 = MFMAs + fragment reads without the DMA stream.  They bound the
-// main loop from both sides (results are garbage by construction).
-#ifndef DADD_IGEMM_EXP
-#define DADD_IGEMM_EXP 0
-#endif
-constexpr int EXP = DADD_IGEMM_EXP;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned OOB = 0x80000000u;   // beyond num_records of every descriptor: the load returns zeros
@@ -45,13 +36,18 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool UPS, bool PERS, bool WS>
-__global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const IgemmArgs p) {
+// Tile BM x BN x 64 with BM in {64, 128}, BN in {64, 128, 160}.  The 64-row tiles exist for the short GEMMs of the
+// 16x16 / 8x8 levels (M = 1024 / 256): they fill the chip without split-K slabs, and two of their workgroups
+// (64 KB of LDS each at 64x64) share a CU, so one's prologue / epilogue hides under the other's K loop.
+template <int BM, int BN, bool UPS, bool PERS>
+__global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type exists only in device code; the host
                                       // pass needs just the launch stub of this signature
+  constexpr bool WS = true;
+  constexpr int WM = BM / 2, MI = WM / 16;   // compute waves: 2 (M) x 2 (N); rows / 16-row fragments per wave
   constexpr int WN = BN / 2;
   constexpr int J = WN / 16;
-  constexpr int NA = BM / 32;   // DMA instructions per wave per tile, activations (4)
+  constexpr int NA = BM / 32;   // DMA instructions per loader wave per tile, activations (2 or 4)
   constexpr int NBJ = BN / 32;  // DMA instructions per wave per tile, weights (4 or 5)
   constexpr int LPT = NA + NBJ;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -190,18 +186,6 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     c.koff = (unsigned)cur_koff;
     return c;
   };
-  auto issue_a = [&](const IssueCtx& c, int i) {
-    if constexpr (!UPS) {
-      const bool ok = (a_mask[i] >> c.tap) & 1u;
-      const unsigned vo = c.second ? a_v2[i] : a_v1[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, ok ? vo : OOB, c.soff, 0, 0);
-    } else {   // nearest-2x upsample: the source pixel is (iy>>1, ix>>1) of the virtual image
-      const int iy = a_y[i] + c.ky, ix = a_x[i] + c.kx;
-      const bool ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
-      const unsigned vo = (unsigned)(((a_pix[i] + (iy >> 1) * p.Wi + (ix >> 1)) * c.cs + a_cc[i]) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsA, (lptr_t)(c.sa + i * 4096), 16, ok ? vo : OOB, c.soff, 0, 0);
-    }
-  };
   auto issue_w = [&](const IssueCtx& c, int j) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsW, (lptr_t)(c.sa + A_BYTES + j * 4096), 16, w_v[j], c.koff, 0, 0);
   };
@@ -239,7 +223,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
   int eff_key = -1;
   auto issue = [&]() {   // whole tile at once (prologue; loader waves)
     const IssueCtx c = issue_begin();
-    if constexpr (EXP != 2) {
+    {
       const int key = c.tap * 2 + (c.second ? 1 : 0) + (PERS ? iss_tile * 32 : 0);
       if (key != eff_key) {                         // wave-uniform
         eff_key = key;
@@ -263,76 +247,54 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     issue_advance();
   };
 
-  f4 acc[J][4];
-
-  // fragment addresses inside a slot: per lane one byte offset per operand and K half (the XOR swizzle
-  // term is the same for all 16-row fragments of a wave), fragment i / j adds an immediate i*2048.
+  // ---- ring protocol (4 stages).  Loader waves: tiles 0..2 up front, then per K tile one counted wait
+  // "all but my youngest tile landed", the workgroup barrier, and the DMA of tile it+3 into the slot that
+  // tile it-1 has just vacated.  Compute waves: one barrier per K tile, MFMAs of tile it while the fragments
+  // of the next K half / next tile are prefetched behind them.  With PERS the stream of K tiles runs across
+  // this workgroup's output tiles (the cursor rolls over inside issue(), including the per-tile address
+  // setup — off the MFMA waves).
+  const int total_kt = tile_count * nk;
+  if (loader) {
+    issue();
+    issue();
+    issue();
+    wait_vmcnt<LPT>();
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < total_kt; ++it) {
+      if (it > 0) {
+        wait_vmcnt<LPT>();   // tile it+1 landed (this wave's share); tile it+2 may be in flight
+        __builtin_amdgcn_s_barrier();
+      }
+      issue();               // tile it+3 -> the slot of tile it-1, free since this barrier
+    }
+    wait_vmcnt<0>();
+    return;
+  }
+  // ---- compute waves
+  f4 acc[J][MI];
+  // fragment addresses inside a slot: per lane one byte offset per operand and K half (the XOR swizzle term is
+  // the same for all 16-row fragments of a wave), fragment i / j adds an immediate i*2048
   const int fq = lane >> 4;
   int fa[2], fb[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    fa[s] = lds_off(wm * 64 + (lane & 15), s * 4 + fq) * 2;
-    fb[s] = A_BYTES + lds_off(wn * WN + (lane & 15), s * 4 + fq) * 2;
+  for (int s2 = 0; s2 < 2; ++s2) {
+    fa[s2] = lds_off(wm * WM + (lane & 15), s2 * 4 + fq) * 2;
+    fb[s2] = A_BYTES + lds_off(wn * WN + (lane & 15), s2 * 4 + fq) * 2;
   }
-  auto read_frags = [&](int slot_off, int s, h8 (&xa)[4], h8 (&wb)[J]) {
-    const char* a = smem + slot_off + fa[s];
-    const char* b = smem + slot_off + fb[s];
+  __builtin_amdgcn_s_barrier();   // tiles 0 and 1 landed
+  __builtin_amdgcn_sched_barrier(0);
+  h8 xa0[MI], wb0[J], xa1[MI], wb1[J];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const h8*>(a + i * 2048);
+  for (int i = 0; i < MI; ++i) xa0[i] = *reinterpret_cast<const h8*>(smem + fa[0] + i * 2048);
 #pragma unroll
-    for (int j = 0; j < J; ++j) wb[j] = *reinterpret_cast<const h8*>(b + j * 2048);
-  };
-  auto mma = [&](const h8 (&xa)[4], const h8 (&wb)[J]) {
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
-  };
-
-  if constexpr (WS) {
-    const int total_kt = tile_count * nk;   // PERS: one stream of K tiles over this workgroup's output tiles
-    if (loader) {
-      // ---- loader waves: same ring protocol, DMA side only (with PERS the cursor rolls from one output
-      // tile into the next inside issue(), including the per-tile address setup — off the MFMA waves)
-      issue();
-      issue();
-      issue();
-      wait_vmcnt<LPT>();
-      __builtin_amdgcn_s_barrier();
-      for (int it = 0; it < total_kt; ++it) {
-        if (it > 0) {
-          wait_vmcnt<LPT>();   // tile it+1 landed (this wave's share); tile it+2 may be in flight
-          __builtin_amdgcn_s_barrier();
-        }
-        issue();               // tile it+3 -> the slot of tile it-1, free since this barrier
-      }
-      wait_vmcnt<0>();
-      return;
-    }
-    // ---- compute waves
-    f4 acc[J][4];
-    const int fq = lane >> 4;
-    int fa[2], fb[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      fa[s2] = lds_off(wm * 64 + (lane & 15), s2 * 4 + fq) * 2;
-      fb[s2] = A_BYTES + lds_off(wn * WN + (lane & 15), s2 * 4 + fq) * 2;
-    }
-    __builtin_amdgcn_s_barrier();   // tiles 0 and 1 landed
-    __builtin_amdgcn_sched_barrier(0);
-    h8 xa0[4], wb0[J], xa1[4], wb1[J];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xa0[i] = *reinterpret_cast<const h8*>(smem + fa[0] + i * 2048);
-#pragma unroll
-    for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb[0] + j * 2048);
-    int comp_off = 0;
-    bool started = false;
-    for (int tl = 0; tl < tile_count; ++tl) {
+  for (int j = 0; j < J; ++j) wb0[j] = *reinterpret_cast<const h8*>(smem + fb[0] + j * 2048);
+  int comp_off = 0;
+  bool started = false;
+  for (int tl = 0; tl < tile_count; ++tl) {
 #pragma unroll
     for (int j = 0; j < J; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < nk; ++it) {
       if (started) __builtin_amdgcn_s_barrier();
       started = true;
@@ -343,24 +305,24 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
       const char* cb1 = smem + comp_off + fb[1];
       const char* na = smem + next_off + fa[0];
       const char* nb = smem + next_off + fb[0];
+      // hand-interleaved: every MFMA is followed by at most one fragment read (MI + J reads behind MI * J MFMAs),
+      // issued in the order the next half consumes them: wb[0], xa[0..MI), wb[1..J)
 #pragma unroll
-      for (int k = 0; k < 4 * J; ++k) {     // first K half; the second half's fragments stream in behind
-        const int jj = k / 4, ii = k % 4;
-        if constexpr (EXP != 1)
-          acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
+      for (int k = 0; k < MI * J; ++k) {     // first K half; the second half's fragments stream in behind
+        const int jj = k / MI, ii = k % MI;
+        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
         if (k == 0) wb1[0] = *reinterpret_cast<const h8*>(cb1);
-        else if (k <= 4) xa1[k - 1] = *reinterpret_cast<const h8*>(ca + (k - 1) * 2048);
-        else if (k < 4 + J) wb1[k - 4] = *reinterpret_cast<const h8*>(cb1 + (k - 4) * 2048);
+        else if (k <= MI) xa1[k - 1] = *reinterpret_cast<const h8*>(ca + (k - 1) * 2048);
+        else if (k < MI + J) wb1[k - MI] = *reinterpret_cast<const h8*>(cb1 + (k - MI) * 2048);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int k = 0; k < 4 * J; ++k) {     // second K half; prefetch of tile it+1's first half
-        const int jj = k / 4, ii = k % 4;
-        if constexpr (EXP != 1)
-          acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
+      for (int k = 0; k < MI * J; ++k) {     // second K half; prefetch of tile it+1's first half
+        const int jj = k / MI, ii = k % MI;
+        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
         if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(nb);
-        else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
-        else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(nb + (k - 4) * 2048);
+        else if (k <= MI) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
+        else if (k < MI + J) wb0[k - MI] = *reinterpret_cast<const h8*>(nb + (k - MI) * 2048);
         __builtin_amdgcn_sched_barrier(0);
       }
       comp_off = next_off;
@@ -368,147 +330,78 @@ __global__ __launch_bounds__(WS ? 512 : 256, 1) void igemm_dma_kernel(const Igem
     }
     int nt, mt;
     tile_decode(p, tile_first + tl, mt, nt);
-    igemm_epilogue<J, 4, 64, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
-    }
-    return;
-  }
-
-  // ---- ring schedule.  Roles at iteration `it`: tile it computes, tile it+1 has LANDED (its first
-  // fragments are prefetched while tile it's second half runs), tiles it+2, it+3 are in flight, and
-  // the slot of tile it-1 (fully read before this iteration's barrier) is the one being refilled.
-  // Every iteration issues exactly LPT DMA loads (dead ones past the end carry zero records), so the
-  // counted wait is a constant and the loop body is ONE basic block the scheduler can interleave.
-  issue();
-  issue();
-  issue();
-  wait_vmcnt<LPT>();   // tiles 0 and 1 landed (this wave's share)
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  h8 xa0[4], wb0[J], xa1[4], wb1[J];
-  read_frags(0, 0, xa0, wb0);
-  int comp_off = 0;
-  bool started = false;
-  for (int tl = 0; tl < tile_count; ++tl) {
-#pragma unroll
-  for (int j = 0; j < J; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
-  for (int it = 0; it < nk; ++it) {
-    if (started) {
-      wait_vmcnt<LPT>();   // tile it+1 landed (tile it+2's group may still be in flight)
-      __builtin_amdgcn_s_barrier();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int n1 = comp_off + STAGE;
-    const int next_off = n1 >= 4 * STAGE ? 0 : n1;
-    // Hand-interleaved body: every MFMA is followed by ONE piece of the other work, so the in-order
-    // wave fills the matrix pipe's 16-cycle issue gaps instead of alternating MFMA-only runs (12 idle
-    // issue cycles each) with DMA/scalar-only runs (matrix pipe idle) — PMC before: MFMA busy 38 %.
-    //   first half  (operands xa0/wb0, prefetched): DMA issue of tile it+3, then the second-half reads
-    //   second half (operands xa1/wb1): prefetch of tile it+1's first-half fragments, cursor advance
-    const IssueCtx ic = issue_begin();
-    const char* ca = smem + comp_off + fa[1];
-    const char* cb1 = smem + comp_off + fb[1];
-    const char* na = smem + next_off + fa[0];
-    const char* nb = smem + next_off + fb[0];
-#pragma unroll
-    for (int k = 0; k < 4 * J; ++k) {
-      const int jj = k / 4, ii = k % 4;
-      if constexpr (EXP != 1)
-        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
-      if (k < NA) { if constexpr (EXP != 2) issue_a(ic, k); }
-      else if (k < LPT) { if constexpr (EXP != 2) issue_w(ic, k - NA); }
-      else {
-        const int r = k - LPT;            // fragment read order = consumption order of the second half
-        if (r == 0) wb1[0] = *reinterpret_cast<const h8*>(cb1);
-        else if (r <= 4) xa1[r - 1] = *reinterpret_cast<const h8*>(ca + (r - 1) * 2048);
-        else if (r < 4 + J) wb1[r - 4] = *reinterpret_cast<const h8*>(cb1 + (r - 4) * 2048);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int k = 0; k < 4 * J; ++k) {
-      const int jj = k / 4, ii = k % 4;
-      if constexpr (EXP != 1)
-        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
-      if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(nb);
-      else if (k <= 4) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
-      else if (k < 4 + J) wb0[k - 4] = *reinterpret_cast<const h8*>(nb + (k - 4) * 2048);
-      else if (k == 4 + J) issue_advance();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    comp_off = next_off;
-    started = true;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (tl == tile_count - 1) wait_vmcnt<0>();   // drain the dead tail loads before the last epilogue
-
-  // ---- epilogue (shared with igemm.hip); with PERS the next tile's DMA loads stay in flight under it
-  int nt, mt;
-  tile_decode(p, tile_first + tl, mt, nt);
-  igemm_epilogue<J, 4, 64, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+    igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
   }
 #endif
 }
 
-template <int BN>
+template <int BM, int BN>
 constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2; }
 
-template <int BN, bool UPS, bool PERS, bool WS>
+template <int BM, int BN, bool UPS, bool PERS>
 int set_attr() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BN, UPS, PERS, WS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BN>()));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, UPS, PERS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
   return DADD_OK;
 }
 
 int g_num_cu = 0;
 
+template <int BM, int BN, bool UPS, bool PERS>
+void launch(const char* name, const IgemmArgs& a, dim3 grid, hipStream_t s) {
+  dadd_launch({name, dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_dma_kernel<BM, BN, UPS, PERS>, grid, dim3(512),
+              smem_bytes<BM, BN>(), s, a);
+}
+
 }  // namespace
 
 int dadd_init_igemm_dma() {
-  int rc = set_attr<128, false, true, true>();
-  if (rc == DADD_OK) rc = set_attr<160, false, true, true>();
-  if (rc == DADD_OK) rc = set_attr<128, false, false, true>();
-  if (rc == DADD_OK) rc = set_attr<128, true, false, true>();
-  if (rc == DADD_OK) rc = set_attr<160, false, false, true>();
-  if (rc == DADD_OK) rc = set_attr<160, true, false, true>();
+  int rc = set_attr<128, 128, false, true>();
+  if (rc == DADD_OK) rc = set_attr<128, 160, false, true>();
+  if (rc == DADD_OK) rc = set_attr<128, 128, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 128, true, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 160, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 160, true, false>();
+  if (rc == DADD_OK) rc = set_attr<64, 64, false, false>();
+  if (rc == DADD_OK) rc = set_attr<64, 128, false, false>();
+  if (rc == DADD_OK) rc = set_attr<64, 160, false, false>();
   int dev = 0;
   DADD_HIP(hipGetDevice(&dev));
   DADD_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   return rc;
 }
 
-// persistent ring over several output tiles: more tiles than CUs, no split-K, no upsample gather
+// persistent ring over several output tiles: 128-row tiles, more tiles than CUs, no split-K, no upsample gather
 bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit) {
-  static const bool no_pers = getenv("DADD_NO_PERSIST") != nullptr;   // A/B measurements only
-  const int total = ((a.M + BM - 1) / BM) * a.ntiles;
-  return !no_pers && (a.flags & DADD_TUNE_PERSIST) && nsplit == 1 && !a.ups && g_num_cu > 0 && total > g_num_cu;
+  return (a.flags & DADD_TUNE_PERSIST) && nsplit == 1 && !a.ups && g_num_cu > 0 && a.mtiles * a.ntiles > g_num_cu;
 }
 
-int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_n, int nsplit, hipStream_t s) {
-  const int mtiles = (a.M + BM - 1) / BM;
-  const int total = mtiles * a.ntiles;
+// `a.mtiles` / `a.ntiles` are the tile counts for (tile_m, tile_n), set by the caller
+int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_m, int tile_n, int nsplit, hipStream_t s) {
+  const int total = a.mtiles * a.ntiles;
   // buffer offsets are 32-bit with bit 31 reserved as the out-of-range marker
   DADD_REQUIRE((size_t)a.B * a.Hi * a.Wi * (size_t)(a.C1 > a.C2 ? a.C1 : a.C2) * 2 < 0x7FF00000ull &&
                    (size_t)a.N * a.K * 2 < 0x7FF00000ull,
                "igemm(dma): operand larger than the 2 GiB buffer window");
-  constexpr int smem160 = smem_bytes<160>(), smem128 = smem_bytes<128>();
-  const double flop = dadd_igemm_flop(a), bytes = dadd_igemm_bytes(a);
-  if (dadd_igemm_dma_persistent(a, nsplit)) {
+  if (tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit)) {
     dim3 grid(g_num_cu);
-    if (tile_n == 160) dadd_launch({"igemm_dma_kernel<160, false, true, true>", flop, bytes}, igemm_dma_kernel<160, false, true, true>, grid, dim3(512), smem160, s, a);
-    else dadd_launch({"igemm_dma_kernel<128, false, true, true>", flop, bytes}, igemm_dma_kernel<128, false, true, true>, grid, dim3(512), smem128, s, a);
+    if (tile_n == 160) launch<128, 160, false, true>("igemm_dma_kernel<128, 160, false, true>", a, grid, s);
+    else launch<128, 128, false, true>("igemm_dma_kernel<128, 128, false, true>", a, grid, s);
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }
   dim3 grid(total, nsplit);
-  if (tile_n == 160) {
-    if (a.ups) dadd_launch({"igemm_dma_kernel<160, true, false, true>", flop, bytes}, igemm_dma_kernel<160, true, false, true>, grid, dim3(512), smem160, s, a);
-    else dadd_launch({"igemm_dma_kernel<160, false, false, true>", flop, bytes}, igemm_dma_kernel<160, false, false, true>, grid, dim3(512), smem160, s, a);
+  if (tile_m == 64) {
+    DADD_REQUIRE(!a.ups, "igemm(dma): the 64-row tiles have no upsample gather");
+    if (tile_n == 160) launch<64, 160, false, false>("igemm_dma_kernel<64, 160, false, false>", a, grid, s);
+    else if (tile_n == 128) launch<64, 128, false, false>("igemm_dma_kernel<64, 128, false, false>", a, grid, s);
+    else launch<64, 64, false, false>("igemm_dma_kernel<64, 64, false, false>", a, grid, s);
+  } else if (tile_n == 160) {
+    if (a.ups) launch<128, 160, true, false>("igemm_dma_kernel<128, 160, true, false>", a, grid, s);
+    else launch<128, 160, false, false>("igemm_dma_kernel<128, 160, false, false>", a, grid, s);
   } else {
-    if (a.ups) dadd_launch({"igemm_dma_kernel<128, true, false, true>", flop, bytes}, igemm_dma_kernel<128, true, false, true>, grid, dim3(512), smem128, s, a);
-    else dadd_launch({"igemm_dma_kernel<128, false, false, true>", flop, bytes}, igemm_dma_kernel<128, false, false, true>, grid, dim3(512), smem128, s, a);
+    if (a.ups) launch<128, 128, true, false>("igemm_dma_kernel<128, 128, true, false>", a, grid, s);
+    else launch<128, 128, false, false>("igemm_dma_kernel<128, 128, false, false>", a, grid, s);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

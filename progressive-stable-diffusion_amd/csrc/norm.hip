@@ -1,7 +1,6 @@
 // GroupNorm(+SiLU) over NHWC fp16 with a fused skip-concat, and LayerNorm — HBM-bound kernels:
 // 16-byte loads/stores, fp32 statistics, wavefront-shuffle / LDS reductions, no atomics (results
 // are bit-reproducible run to run).
-#include <cstdlib>
 #include "dadd_common.h"
 
 namespace {
@@ -106,48 +105,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
   }
 }
 
-// pass 2 (tiny): combine the chunk partials of one batch sample in a fixed order (double), write
-// mean / rstd per group.  grid (B), 256 threads = 32 groups x 8 lanes.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const GnArgs p) {
-  const int t = threadIdx.x, b = blockIdx.x;
-  const int g = t >> 3, sub = t & 7;
-  double a = 0.0, q = 0.0;
-  if (g < p.groups) {
-    // four chunk partials in flight per thread (a loop of single dependent loads made this 6 us for 32 KB)
-    for (int k = sub; k < p.nchunk; k += 32) {
-      float2 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = k + 8 * u;
-        v[u] = kk < p.nchunk ? *reinterpret_cast<const float2*>(p.ws + (((size_t)b * p.nchunk + kk) * p.groups + g) * 2)
-                             : float2{0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a += (double)v[u].x;
-        q += (double)v[u].y;
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 4; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    q += __shfl_xor(q, o, 64);
-  }
-  if (g < p.groups && sub == 0) {
-    const double n = (double)p.HW * (double)p.cg;
-    const double mu = a / n;
-    double var = q / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    float* o2 = p.stats + ((size_t)b * p.groups + g) * 2;
-    o2[0] = (float)mu;
-    o2[1] = (float)(1.0 / sqrt(var + (double)p.eps));
-  }
-}
-
-// pass 3: fold gamma/beta into per-channel scale/shift (C values per block), apply to this block's
-// rows.  grid (row blocks, B).  FIN = the block combines the chunk partials itself (few chunks: saves
-// the finalize launch, which costs more than it buys on the small feature maps).
+// pass 2: every block combines the (<= 64) chunk partials of its sample in a fixed order (double), folds
+// gamma/beta into per-channel scale/shift (C values per block) and applies them to its rows.  grid (row blocks, B).
+// (A separate finalize launch cost 5 us per GroupNorm for 16 KB of partials.)
 template <bool FIN>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
   extern __shared__ float sm[];  // [C] scale, [C] shift, [2*groups] mean/rstd (FIN)
@@ -299,6 +259,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs p) {
   }
 }
 
+constexpr int GN_CHUNK_MAX = 64;
 constexpr int GN_FUSED_MAX_BYTES = 16 * 1024;   // measured: wins only below ~16 KiB per (batch, group) slab
 
 // LayerNorm: one wave per row, the row lives in registers (exact two-pass variance).
@@ -389,18 +350,15 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const int nvec = C / 8;
   p.TV = nvec < 256 ? nvec : 256;
   p.RP = 256 / p.TV;
-  // stat chunks: at least two passes of rows per block, at most 128 per sample
+  // stat chunks: at least two passes of rows per block, at most GN_CHUNK_MAX per sample (few enough that every
+  // apply block combines them itself: no finalize launch)
   int nchunk = HW / (2 * p.RP > 16 ? 2 * p.RP : 16);
-  static const int chunk_max = getenv("DADD_GN_CHUNK_MAX") ? atoi(getenv("DADD_GN_CHUNK_MAX")) : 128;   // A/B only
-  if (nchunk > chunk_max) nchunk = chunk_max;
+  if (nchunk > GN_CHUNK_MAX) nchunk = GN_CHUNK_MAX;
   if (nchunk < 1) nchunk = 1;
-  if (nchunk > DADD_GN_MAX_CHUNKS - 1) nchunk = DADD_GN_MAX_CHUNKS - 1;
   p.stats = ws + (size_t)B * (DADD_GN_MAX_CHUNKS - 1) * groups * 2;   // last chunk slot of the workspace
   p.rows_per_chunk = (HW + nchunk - 1) / nchunk;
   p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
-  static const int fin_max = getenv("DADD_GN_FIN_MAX") ? atoi(getenv("DADD_GN_FIN_MAX")) : 64;   // A/B only
-  const bool fin_in_apply = nchunk <= fin_max;   // measured: the extra launch only pays on big maps
-  p.rows_per_block = (fin_in_apply ? 4 : 8) * p.RP;
+  p.rows_per_block = 8 * p.RP;
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t slab_bytes = (size_t)HW * p.cg * sizeof(half_t);
@@ -414,13 +372,7 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
   dadd_launch({"gn_stats_kernel", 0.0, act_bytes}, gn_stats_kernel, dim3(p.nchunk, B), dim3(256), (unsigned)sm1, s, p);
   DADD_LAUNCH_CHECK();
-  if (fin_in_apply) {
-    dadd_launch({"gn_apply_kernel<true>", 0.0, act_bytes * 2.0}, gn_apply_kernel<true>, dim3(nrb, B), dim3(256), (unsigned)sm2, s, p);
-  } else {
-    dadd_launch({"gn_finalize_kernel", 0.0, (double)B * p.nchunk * groups * 8.0}, gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
-    DADD_LAUNCH_CHECK();
-    dadd_launch({"gn_apply_kernel<false>", 0.0, act_bytes * 2.0}, gn_apply_kernel<false>, dim3(nrb, B), dim3(256), (unsigned)sm2, s, p);
-  }
+  dadd_launch({"gn_apply_kernel<true>", 0.0, act_bytes * 2.0}, gn_apply_kernel<true>, dim3(nrb, B), dim3(256), (unsigned)sm2, s, p);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

@@ -79,8 +79,8 @@ def geglu_interleave(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, to
 
 def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False,
                   residual: bool = True) -> Tuple[int, int, int]:
-    """(tile_m, splitk, tune_flags) for one implicit GEMM, from measurements over every layer shape
-    of the B=4 / 512x512 step on MI355X (scripts/op_bench.py, profiles/r01_*_op_bench.txt):
+    """(tile_m, splitk, tune_flags) for one implicit GEMM with 128- or 160-column tiles, from measurements over
+    every layer shape of the B=4 / 512x512 step on MI355X (scripts/op_bench.py, profiles/r01_*_op_bench.txt):
       * K >= 12 tiles: the wave-specialised LDS-DMA ring kernel, 128-row tiles, ONE workgroup per CU;
         split K only while a slice keeps >= 16 K tiles (8-10 on the small 8x8..32x32 grids) and the grid
         stays near 256 workgroups — the fp32 slabs and the finish kernel cost more than idle CUs below that;
@@ -117,6 +117,36 @@ def choose_splitk(m: int, n: int, k: int, tile_n: int) -> int:
     return choose_tiling(m, n, k, tile_n)[1]
 
 
+# Measured tile table: (m, n, k, taps, geglu, residual, ups, stride) -> (tile_m, tile_n, splitk, tune), written by
+# scripts/tile_sweep.py from in-situ per-launch timings of the B=4 / 512x512 step; shapes outside it use the rules of
+# choose_tiling().  TILING_OVERRIDE (same keys) is the sweep's own hook and wins over both.
+TILING_OVERRIDE: Dict[Tuple, Tuple[int, int, int, int]] = {}
+try:
+    from .tiling_table import TABLE as TILING_TABLE
+except ImportError:          # no table committed yet
+    TILING_TABLE = {}
+
+
+def tiling_key(m, n, k, taps, geglu, residual, ups=0, stride=1):
+    return (int(m), int(n), int(k), int(taps), bool(geglu), bool(residual), int(bool(ups)), int(stride))
+
+
+def plan_tiling(m, n, k, taps, geglu, residual, ups=0, stride=1) -> Tuple[int, int, int, int]:
+    """(tile_m, tile_n, splitk, tune) of one implicit GEMM."""
+    key = tiling_key(m, n, k, taps, geglu, residual, ups, stride)
+    hit = TILING_OVERRIDE.get(key) or TILING_TABLE.get(key)
+    if hit is not None:
+        return tuple(hit)
+    tile_n = 128 if geglu or n % 160 else 160
+    tile_m, sk, tune = choose_tiling(m, n, k, tile_n, geglu, residual)
+    # short linears of the small maps (<= 128 tiles of 128 rows): 64x64 LDS-DMA tiles, two workgroups per CU, fill
+    # the chip without fp32 slabs and a finish launch
+    if (taps == 1 and not geglu and not ups and n % 64 == 0 and k // 64 <= 40
+            and math.ceil(m / 128) * math.ceil(n / tile_n) <= N_CU // 2):
+        return 64, 64, 1, 0
+    return tile_m, tile_n, sk, tune
+
+
 class Pool:
     """Plan-time buffer pool: fixed addresses, explicit release, reuse by (shape, dtype)."""
 
@@ -141,8 +171,9 @@ class Pool:
 
 
 class _Plan:
-    def __init__(self, be):
+    def __init__(self, be, wcache=None):
         self.be = be
+        self.wcache = wcache
         self.pool = Pool(be)
         self.ops: List = []
         self.keep: List[torch.Tensor] = []  # weights & persistent buffers
@@ -165,14 +196,26 @@ class _Plan:
         self.keep.append(d)
         return d
 
+    def cached(self, key, make):
+        """Device tensor for ``key`` from the optional cross-plan cache (``wcache``: plans for other batch sizes
+        or tilings over the same state dict share the packed weights instead of re-packing 1.9 GB each)."""
+        if self.wcache is None:
+            return make()
+        t = self.wcache.get(key)
+        if t is None:
+            t = self.wcache[key] = make()
+        else:
+            self.keep.append(t)
+        return t
+
     # ---- recorded building blocks -----------------------------------------------------------
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
              stride=1, ups=0, pad=1, flags=0):
         out = self.pool.get(out_shape)
         n = w.shape[0]
-        tile_n = 128 if (flags & L.EPI_GEGLU) or n % 160 else 160
         m = out_shape[0] * out_shape[1] * out_shape[2]
-        tile_m, sk, tune = choose_tiling(m, n, w.shape[1], tile_n, bool(flags & L.EPI_GEGLU), residual is not None)
+        tile_m, tile_n, sk, tune = plan_tiling(m, n, w.shape[1], taps, bool(flags & L.EPI_GEGLU), residual is not None,
+                                               ups, stride)
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | tune
@@ -194,8 +237,8 @@ class UNetPlan(_Plan):
     """SD-1.x UNet forward for a fixed (B, S); eps = plan(latents) with cond/time prepared apart."""
 
     def __init__(self, be, sd: Dict[str, torch.Tensor], batch: int, side: int, *,
-                 prefix="unet.unet", use_routing_gates=True, use_frequency_strategy=True):
-        super().__init__(be)
+                 prefix="unet.unet", use_routing_gates=True, use_frequency_strategy=True, wcache=None):
+        super().__init__(be, wcache)
         assert side % 8 == 0, "latent side must be a multiple of 8 (three stride-2 levels)"
         self.B, self.S = batch, side
         self.gates_mode = use_routing_gates
@@ -282,10 +325,10 @@ class UNetPlan(_Plan):
         return s
 
     def w(self, key, pack=pack_conv):
-        return self.dev(pack(self.sd[self.prefix + key]))
+        return self.cached((self.prefix + key, pack.__name__), lambda: self.dev(pack(self.sd[self.prefix + key])))
 
     def f(self, key):
-        return self.dev(self.sd[self.prefix + key].float())
+        return self.cached((self.prefix + key, "f32"), lambda: self.dev(self.sd[self.prefix + key].float()))
 
     # -- blocks ----------------------------------------------------------------------------------
     def _resnet(self, name, x, skip=None):
@@ -323,7 +366,8 @@ class UNetPlan(_Plan):
         ln = self.pool.get(shp)
         # attn1 (self)
         self.rec(self.be.layernorm, hs, self.f(tb + ".norm1.weight"), self.f(tb + ".norm1.bias"), ln)
-        wqkv = self.dev(torch.cat([self.sd[self.prefix + tb + f".attn1.to_{n}.weight"] for n in "qkv"]), F16)
+        wqkv = self.cached((self.prefix + tb, "qkv"), lambda: self.dev(
+            torch.cat([self.sd[self.prefix + tb + f".attn1.to_{n}.weight"] for n in "qkv"]), F16))
         qkv = self.conv(ln, wqkv, (b, h, w_, 3 * c), taps=1, pad=0)
         att = self.pool.get(shp)
         self.rec(self.be.self_attn, qkv.view(b, h * w_, 3 * c), att.view(b, h * w_, c), HEADS)
@@ -347,10 +391,14 @@ class UNetPlan(_Plan):
         self.pool.put(h2, att)
         # GEGLU feed-forward
         self.rec(self.be.layernorm, h3, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"), ln)
-        wf, bf = geglu_interleave(self.sd[self.prefix + tb + ".ff.net.0.proj.weight"],
-                                  self.sd[self.prefix + tb + ".ff.net.0.proj.bias"])
-        ff = self.conv(ln, self.dev(wf, F16), (b, h, w_, 4 * c), bias=self.dev(bf.float()), taps=1,
-                       pad=0, flags=L.EPI_GEGLU)
+        def _geglu():
+            wf, bf = geglu_interleave(self.sd[self.prefix + tb + ".ff.net.0.proj.weight"],
+                                      self.sd[self.prefix + tb + ".ff.net.0.proj.bias"])
+            return self.dev(wf, F16), self.dev(bf.float())
+        wf, bf = self.cached((self.prefix + tb, "geglu"), _geglu)
+        if self.wcache is not None:
+            self.keep += [wf, bf]
+        ff = self.conv(ln, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU)
         self.pool.put(ln)
         h4 = self.conv(ff, self.w(tb + ".ff.net.2.weight"), shp, bias=self.f(tb + ".ff.net.2.bias"),
                        residual=h3, taps=1, pad=0)

@@ -85,6 +85,35 @@ def test_igemm_conv3x3(hip, cin, cout, h, stride, ups, pad):
     close(o, o_ref, 3e-3, 2e-3, f"conv3x3 cin{cin} s{stride} u{ups} p{pad}")
 
 
+@pytest.mark.parametrize("tile_m,tile_n", [(64, 64), (64, 128), (64, 160), (128, 128), (128, 160)])
+@pytest.mark.parametrize("case", ["linear_ragged", "linear_res_splitk", "conv3x3", "conv_stride2_concat"])
+def test_igemm_dma_tile_shapes(hip, tile_m, tile_n, case):
+    """Every (rows, columns) instantiation of the wave-specialised LDS-DMA kernel — 64-row tiles for the short GEMMs
+    of the small maps, 128-row tiles elsewhere — on ragged M / N, residual + bias + time row, split-K through the
+    finish kernel, a 3x3 gather with padding and a strided 3x3 over a skip-concat."""
+    kw = dict(tile_m=tile_m, tile_n=tile_n)
+    if case == "linear_ragged":
+        m, n, k = 1000, 832 if tile_n != 160 else 800, 640          # M, N not multiples of the tile
+        x, w = rnd((1, m, 1, k), 60), rnd((n, k), 61, 1 / math.sqrt(k))
+        o, o_ref = run_igemm(hip, x, w, (1, m, 1, n), bias=rnd((n,), 62, 0.1, F32), flags=1, **kw)
+    elif case == "linear_res_splitk":
+        b, hw, n, k = 2, 256, 1280, 2560
+        x, w = rnd((b, hw, 1, k), 63), rnd((n, k), 64, 1 / math.sqrt(k))
+        o, o_ref = run_igemm(hip, x, w, (b, hw, 1, n), bias=rnd((n,), 65, 0.1, F32), residual=rnd((b, hw, 1, n), 66),
+                             rowvec=rnd((b, n), 67, 0.3, F32), flags=7, splitk=4, in_launch_combine=False, **kw)
+    elif case == "conv3x3":
+        b, h, cin, cout = 2, 12, 128, 320
+        x, w = rnd((b, h, h, cin), 68), rnd((cout, 9 * cin), 69, 1 / math.sqrt(9 * cin))
+        o, o_ref = run_igemm(hip, x, w, (b, h, h, cout), bias=rnd((cout,), 70, 0.1, F32), taps=9, pad=1, flags=1, **kw)
+    else:
+        b, h, c1, c2, n = 2, 16, 192, 128, 640
+        x, x2 = rnd((b, h, h, c1), 71), rnd((b, h, h, c2), 72)
+        w = rnd((n, 9 * (c1 + c2)), 73, 1 / math.sqrt(9 * (c1 + c2)))
+        o, o_ref = run_igemm(hip, x, w, (b, h // 2, h // 2, n), x2=x2, bias=rnd((n,), 74, 0.1, F32), taps=9, stride=2,
+                             pad=1, flags=1, **kw)
+    close(o, o_ref, 3e-3, 2e-3, f"dma tile {tile_m}x{tile_n} {case}")
+
+
 @pytest.mark.parametrize("taps", [1, 9])
 def test_igemm_skip_concat(hip, taps):
     b, h, c1, c2, n = 2, 8, 640, 320, 640
