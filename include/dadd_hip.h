@@ -85,7 +85,8 @@ int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 /* ---- the two thin-channel convolutions at the UNet / VAE ends ------------------------------
  * conv_in : x fp16 NHWC with 8 stored channels (4 or 3 real) -> fp16 NHWC Cout.
  * conv_out: fp16 NHWC C -> fp32 NCHW Cout<=4; mode 1 also applies clamp(-1,1),(x+1)/2,clamp(0,1)
- * (= _latents_to_images tail, src/pipelines/inference/inference_pipeline_ip.py:484-486). */
+ * (= _latents_to_images tail, src/pipelines/inference/inference_pipeline_ip.py:484-486); mode 2 clamps to
+ * [-30, 20] (the logvar half of the VAE encoder moments, diffusers DiagonalGaussianDistribution). */
 int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* bias, void* out, int B, int H,
                           int W, int Cout, void* stream);
 int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw, int B,
@@ -96,6 +97,12 @@ int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, floa
  * Replaces latents / latent_scale (inference_pipeline_ip.py:476) + layout change. */
 int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B, int C, int H, int W,
                                     float scale, const float* mat, const float* vec, void* stream);
+
+/* out = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale over n fp32 elements:
+ * AutoencoderKL.encode(x).latent_dist.sample() * latent_scale (src/models/vae/vae.py:71-88,
+ * src/models/diffusion_module_ip.py:410-411) with the noise supplied by the caller. */
+int dadd_gaussian_sample_f32(const float* mean, const float* logvar, const float* noise, float scale,
+                             float* out, int64_t n, void* stream);
 
 /* ---- normalisation -------------------------------------------------------------------------
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated

@@ -97,6 +97,11 @@ class HipBackend:
         L.check(self.lib.dadd_conv3x3_cout4_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, c, co,
                                                 int(mode), self.s))
 
+    def gaussian_sample(self, mean, logvar, noise, out, scale=1.0):
+        assert mean.shape == logvar.shape == noise.shape == out.shape and mean.dtype == torch.float32
+        L.check(self.lib.dadd_gaussian_sample_f32(_p(mean), _p(logvar), _p(noise), float(scale), _p(out),
+                                                  mean.numel(), self.s))
+
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None):
         """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU)."""

@@ -115,6 +115,8 @@ __global__ __launch_bounds__(256) void conv_cout4_kernel(const half_t* __restric
       v = fminf(fmaxf(v, -1.f), 1.f);
       v = (v + 1.f) / 2.f;
       v = fminf(fmaxf(v, 0.f), 1.f);
+    } else if (mode == 2) {
+      v = fminf(fmaxf(v, -30.f), 20.f);    // DiagonalGaussianDistribution clamps logvar on construction
     }
     out[((size_t)b * Cout + sub) * H * W + rem] = v;
   }
@@ -217,7 +219,30 @@ __global__ __launch_bounds__(256) void ddim_kernel(float* __restrict__ x, const 
   }
 }
 
+// z = (mean + exp(0.5 * logvar) * noise) * scale : DiagonalGaussianDistribution.sample() followed by the
+// latent scale (diffusers AutoencoderKL; src/models/diffusion_module_ip.py:410-411)
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ mean,
+                                                              const float* __restrict__ logvar,
+                                                              const float* __restrict__ noise, float scale,
+                                                              float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float lv = fminf(fmaxf(logvar[i], -30.f), 20.f);
+    out[i] = (mean[i] + expf(0.5f * lv) * noise[i]) * scale;
+  }
+}
+
 }  // namespace
+
+extern "C" int dadd_gaussian_sample_f32(const float* mean, const float* logvar, const float* noise, float scale,
+                                        float* out, int64_t n, void* stream) {
+  DADD_REQUIRE(mean && logvar && noise && out && n > 0, "gaussian_sample: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  dadd_launch({"gaussian_sample_kernel", 0.0, (double)n * 16.0}, gaussian_sample_kernel, dim3(blocks), dim3(256), 0,
+              static_cast<hipStream_t>(stream), mean, logvar, noise, scale, out, n);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
 
 extern "C" int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B, int C, int H, int W,
                                                float scale, const float* mat, const float* vec,
@@ -253,6 +278,7 @@ extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float*
   DADD_REQUIRE(x && w && out_nchw, "conv_cout4: null pointer");
   DADD_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && Cout >= 1 && Cout <= 4,
                "conv_cout4: C must be x8 and Cout in 1..4");
+  DADD_REQUIRE(mode >= 0 && mode <= 2, "conv_cout4: mode must be 0, 1 or 2");
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(w), "conv_cout4: pointers must be 16-byte aligned");
   const int npix = B * H * W;
   dadd_launch({"conv_cout4_kernel", 2.0 * npix * Cout * 9.0 * C, (double)npix * (2.0 * C + 4.0 * Cout)}, conv_cout4_kernel, dim3((npix + 15) / 16), dim3(256), 0,

@@ -349,9 +349,9 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
-  const bool dma = (d->flags & DADD_TUNE_NODMA) == 0;
+  // (the 64-row LDS-DMA tiles have no upsample gather: such a request runs on the register-staged kernel)
+  const bool dma = (d->flags & DADD_TUNE_NODMA) == 0 && !(tile_m == 64 && a.ups);
   DADD_REQUIRE(tile_n != 64 || (dma && tile_m == 64 && !geglu), "igemm: 64-column tiles exist for the 64-row LDS-DMA kernel only");
-  DADD_REQUIRE(!(dma && tile_m == 64 && a.ups), "igemm: the 64-row LDS-DMA tiles have no upsample gather");
   // persistent ring: a workgroup walks a contiguous run of tiles; with the column tile fastest the run
   // keeps ONE activation row tile (L2-hot after the first tile) and streams the weight tiles
   if (dma && tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit)) a.gm = a.gn = 0;

@@ -189,6 +189,7 @@ class SDVAE:
     def __init__(self, be, sd, batch, side, latent_scale):
         self._be, self._sd = be, sd
         self._plans: Dict[Tuple[int, int], VaeDecoderPlan] = {}
+        self._enc_plans: Dict[Tuple[int, int], Any] = {}
         self._latent_scale = latent_scale
         self._plan(batch, side)
 
@@ -220,8 +221,65 @@ class SDVAE:
         out = img * 2.0 - 1.0
         return SimpleNamespace(sample=out) if return_dict else out
 
+    def _enc_plan(self, batch, side):
+        from .engine import VaeEncoderPlan
+        p = self._enc_plans.get((batch, side))
+        if p is None:
+            if "vae.vae.encoder.conv_in.weight" not in self._sd:
+                raise KeyError("the state dict holds no VAE encoder ('vae.vae.encoder.*'): encode() is unavailable")
+            p = self._enc_plans[(batch, side)] = VaeEncoderPlan(self._be, self._sd, batch, side)
+        return p
+
+    @torch.no_grad()
     def encode(self, images, *, return_dict: bool = True):
-        raise NotImplementedError("SDVAE.encode (training path, SURVEY.md §8 a15) is not built yet")
+        """(vae.py:71-88) images (B,3,H,W) in [-1,1] -> ``.latent_dist`` with ``mean`` / ``logvar`` (clamped to
+        [-30,20]) / ``std`` / ``var`` / ``mode()`` / ``sample(generator=None)``, as diffusers'
+        ``AutoencoderKLOutput`` + ``DiagonalGaussianDistribution``."""
+        b, c, h, w = images.shape
+        if c != 3 or h != w or h % 8:
+            raise ValueError(f"images must be (B, 3, S, S) with S a multiple of 8, got {tuple(images.shape)}")
+        plan = self._enc_plan(b, h // 8)
+        be = self._be
+        x = images.float().contiguous()
+        be.wait_current()
+        be.copy_(plan.img_in, x)
+        plan.run()
+        dist = DiagonalGaussian(be, be.clone(plan.mean), be.clone(plan.logvar))
+        be.release_to_current()
+        return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
+
+
+class DiagonalGaussian:
+    """The slice of diffusers' ``DiagonalGaussianDistribution`` the reference touches (``.sample()`` at
+    src/models/diffusion_module_ip.py:410-411); sampling runs in the HIP library."""
+
+    def __init__(self, be, mean, logvar):
+        self._be, self.mean, self.logvar = be, mean, logvar       # logvar already clamped to [-30, 20]
+
+    @property
+    def std(self):
+        return torch.exp(0.5 * self.logvar)
+
+    @property
+    def var(self):
+        return torch.exp(self.logvar)
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None, *, noise=None, scale: float = 1.0):
+        """mean + std * noise (``scale`` folds the latent scale of the training step in).  ``noise`` injects the
+        draw (parity tests: CPU and device RNG streams differ)."""
+        be = self._be
+        if noise is None:
+            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=torch.float32)
+        else:
+            noise = noise.to(device=self.mean.device, dtype=torch.float32).contiguous()
+        be.wait_current()
+        out = be.empty(self.mean.shape, torch.float32)
+        be.gaussian_sample(self.mean, self.logvar, noise, out, scale)
+        be.release_to_current()
+        return out
 
 
 class DiffusionModuleWithIP:
@@ -246,7 +304,8 @@ class DiffusionModuleWithIP:
             clip_config = clip_config_from_state_dict(
                 {k[len(clip_pref):]: v for k, v in state_dict.items() if k.startswith(clip_pref)})
         shapes = dict(W.unet_shapes(routing_gates=routing))
-        shapes.update(W.vae_shapes(encoder=False))
+        has_enc = state_dict is None or "vae.vae.encoder.conv_in.weight" in state_dict
+        shapes.update(W.vae_shapes(encoder=has_enc))
         shapes.update(W.conditioning_shapes(
             num_classes=emb.num_classes, dim=cfg.model.embedding_dim, num_tokens=dc.num_aoe_tokens,
             clip_hidden=(clip_config or {}).get("hidden_size", 1024),

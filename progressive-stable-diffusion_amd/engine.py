@@ -633,6 +633,63 @@ class VaeDecoderPlan(_Plan):
         self.pool.put(h, g)
 
 
+# ----------------------------------------------------------------------------- VAE encoder
+class VaeEncoderPlan(VaeDecoderPlan):
+    """``SDVAE.encode`` (src/models/vae/vae.py:71-88) -> diffusers ``AutoencoderKL.encode``: images (B,3,H,W) in
+    [-1,1] -> moments (mean, logvar), each (B,4,H/8,W/8) fp32 NCHW.  Same kernels as the decoder; the three
+    downsamplers are 3x3 / stride-2 convolutions with the asymmetric (0,1,0,1) padding folded into the gather
+    (pad = 0: the window runs one pixel past the bottom / right edge, where the gather returns zeros), and
+    ``quant_conv`` (1x1, 8 -> 8) is composed into ``conv_out`` at plan time (two linear maps: exact algebra, one
+    rounding of the composed weights to fp16).  ``side`` is the LATENT side (image side / 8)."""
+
+    def __init__(self, be, sd, batch: int, side: int, *, prefix="vae.vae", wcache=None):
+        _Plan.__init__(self, be, wcache)
+        self.B, self.S = batch, side
+        self.sd, self.prefix = sd, prefix + "."
+        self.gn_ws = be.empty((batch * L.GN_MAX_CHUNKS * GROUPS * 2,), F32)
+        self.img_in = be.zeros((batch, 3, side * 8, side * 8), F32)
+        self.mean = be.zeros((batch, 4, side, side), F32)
+        self.logvar = be.zeros((batch, 4, side, side), F32)
+        self._build()
+
+    def _build(self):
+        b, s = self.B, self.S * 8
+        e = "encoder."
+        x8 = self.pool.get((b, s, s, 8))
+        self.rec(self.be.pack_latents, self.img_in, x8)
+        h = self.pool.get((b, s, s, VAE_CH[0]))
+        self.rec(self.be.conv_cin8, x8, self.w(e + "conv_in.weight", pack_conv_cin8), self.f(e + "conv_in.bias"), h)
+        self.pool.put(x8)
+        for i in range(4):
+            for j in range(2):
+                hn = self._res(e + f"down_blocks.{i}.resnets.{j}", h)
+                self.pool.put(h)
+                h = hn
+            if i < 3:
+                c = h.shape[-1]
+                hn = self.conv(h, self.w(e + f"down_blocks.{i}.downsamplers.0.conv.weight"),
+                               (b, h.shape[1] // 2, h.shape[2] // 2, c),
+                               bias=self.f(e + f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=0)
+                self.pool.put(h)
+                h = hn
+        for blk in (lambda x: self._res(e + "mid_block.resnets.0", x),
+                    lambda x: self._attn(e + "mid_block.attentions.0", x),
+                    lambda x: self._res(e + "mid_block.resnets.1", x)):
+            hn = blk(h)
+            self.pool.put(h)
+            h = hn
+        g = self.gn(h, None, self.f(e + "conv_norm_out.weight"), self.f(e + "conv_norm_out.bias"), 1e-6, 1)
+        # moments = quant_conv(conv_out(g)):  W' = Q W,  b' = Q b + q   (Q: 8x8 of the 1x1 conv)
+        u = self.prefix
+        q = self.sd[u + "quant_conv.weight"].reshape(8, 8).double()
+        w = self.sd[u + e + "conv_out.weight"].double()
+        wq = torch.einsum("oc,cikl->oikl", q, w).float()
+        bq = (q @ self.sd[u + e + "conv_out.bias"].double() + self.sd[u + "quant_conv.bias"].double()).float()
+        self.rec(self.be.conv_cout4, g, self.dev(pack_conv_cout4(wq[:4])), self.dev(bq[:4].contiguous()), self.mean, 0)
+        self.rec(self.be.conv_cout4, g, self.dev(pack_conv_cout4(wq[4:])), self.dev(bq[4:].contiguous()), self.logvar, 2)
+        self.pool.put(h, g)
+
+
 # ----------------------------------------------------------------------------- DDIM loop
 class DdimLoop:
     """Deterministic (eta = 0) DDIM loop over a UNetPlan: ONE captured step graph, replayed."""

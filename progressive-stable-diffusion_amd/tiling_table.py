@@ -1,0 +1,19 @@
+"""Measured GEMM tile table (scripts/tile_sweep.py on MI355X, in-situ per-launch timings of the B=4 / 512x512 step,
+gpurun_out/r02b/tile_sweep.txt -> profiles/r02_b_tile_sweep.txt; see engine.plan_tiling).
+key = (M, N, K, taps, geglu, residual, ups, stride) -> (tile_m, tile_n, splitk, tune).
+Only entries that beat the rules of engine.choose_tiling / plan_tiling by > 3 % are listed; where a split-K variant
+won by less than the ~1.5 us a second (finish) launch costs inside the graph, the single-pass variant is kept."""
+TABLE = {
+    (256, 1280, 2560, 1, False, False, 0, 1): (64, 64, 2, 0),
+    (1024, 1280, 2560, 1, False, False, 0, 1): (128, 160, 4, 0),
+    (1024, 10240, 1280, 1, True, False, 0, 1): (128, 128, 1, 64),
+    (4096, 640, 320, 1, False, False, 0, 1): (64, 160, 1, 0),
+    (4096, 640, 640, 1, False, False, 0, 1): (64, 160, 1, 0),
+    (4096, 640, 640, 1, False, True, 0, 1): (64, 160, 1, 0),
+    (4096, 640, 960, 1, False, False, 0, 1): (64, 160, 1, 0),
+    (4096, 640, 1280, 1, False, False, 0, 1): (64, 160, 1, 0),
+    (4096, 640, 1920, 1, False, False, 0, 1): (64, 160, 1, 0),
+    (4096, 640, 2560, 1, False, True, 0, 1): (64, 160, 1, 0),
+    (16384, 320, 960, 1, False, False, 0, 1): (128, 160, 1, 0),
+    (16384, 2560, 320, 1, True, False, 0, 1): (128, 128, 1, 32),
+}

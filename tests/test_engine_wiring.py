@@ -203,3 +203,48 @@ def test_module_protocol_and_errors(full_sd):
         _module(bad, full_sd)
     with pytest.raises(ValueError):
         mod(torch.zeros(2, 4, 8, 8), torch.zeros(2, dtype=torch.long), torch.zeros(2, 3, 4, 768))
+
+
+def test_vae_encoder_plan_matches_oracle():
+    """``SDVAE.encode`` wiring (asymmetric stride-2 padding, quant_conv composed into conv_out, logvar clamp,
+    reparameterised sample with injected noise) through the torch test backend vs the oracle."""
+    from oracle.sd_vae import vae_encode_moments, vae_encode_sample
+    sd = W.init_state_dict(W.vae_shapes(decoder=False), 3)
+    b, s = 2, 4
+    plan = E.VaeEncoderPlan(TorchRefBackend(), sd, b, s)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(b, 3, 8 * s, 8 * s, generator=g) * 2 - 1
+    noise = torch.randn(b, 4, s, s, generator=g)
+    with torch.no_grad():
+        mean, logvar = vae_encode_moments(sd, x)
+        ref = vae_encode_sample(sd, x, noise) * 0.18215
+    plan.img_in.copy_(x)
+    plan.run()
+    assert (plan.mean - mean).abs().max().item() < 2e-2 * max(1.0, mean.abs().max().item())
+    assert (plan.logvar - logvar).abs().max().item() < 2e-2 * max(1.0, logvar.abs().max().item())
+    out = torch.zeros_like(mean)
+    plan.be.gaussian_sample(plan.mean, plan.logvar, noise, out, 0.18215)
+    assert (out - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_module_vae_encode_protocol(full_sd):
+    """``module.vae.encode(x).latent_dist.sample()`` (diffusion_module_ip.py:410-411) on the module facade."""
+    from oracle.sd_vae import vae_encode_sample
+    sd = dict(full_sd)
+    sd.update(W.init_state_dict(W.vae_shapes(decoder=False), 0))
+    mod = _module(default_config(**{"dataset.image_size": 64}), sd)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    dist = mod.vae.encode(x).latent_dist
+    z = dist.sample(noise=noise) * mod.diff_cfg.latent_scale
+    with torch.no_grad():
+        ref = vae_encode_sample(sd, x, noise) * 0.18215
+    assert z.shape == (2, 4, 8, 8) and (z - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    assert torch.equal(dist.mode(), dist.mean) and float(dist.logvar.max()) <= 20.0 and torch.allclose(dist.std ** 2, dist.var)
+    assert dist.sample().shape == (2, 4, 8, 8)                       # device RNG path
+    with pytest.raises(ValueError):
+        mod.vae.encode(torch.zeros(1, 3, 60, 60))
+    no_enc = _module(default_config(**{"dataset.image_size": 64}), full_sd)
+    with pytest.raises(KeyError):
+        no_enc.vae.encode(x)

@@ -86,7 +86,12 @@ class TorchRefBackend:
         y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, None if bias is None else bias.float(), padding=1)
         if mode == 1:
             y = ((y.clamp(-1, 1) + 1.0) / 2.0).clamp(0, 1)
+        elif mode == 2:
+            y = y.clamp(-30.0, 20.0)
         out.copy_(y)
+
+    def gaussian_sample(self, mean, logvar, noise, out, scale=1.0):
+        out.copy_((mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise) * scale)
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None):
