@@ -35,6 +35,9 @@ extern "C" {
 #define DADD_EPI_ROWVEC 2   /* + rowvec[b][n]   (time-embedding projection of the sample) */
 #define DADD_EPI_RESIDUAL 4 /* + residual[m][n] */
 #define DADD_EPI_GEGLU 8    /* out[m][n/2] = hidden * gelu(gate); weight rows pre-interleaved */
+#define DADD_EPI_LNFOLD 128 /* a LayerNorm over the K (= channel) axis of x folded into this linear: w carries gamma,
+                              bias the composed (w beta + b), ln_c1[n] = sum_k w[n][k]; the kernel derives the row
+                              mean / rstd from the A fragments it reads anyway: out = rstd (acc - mu c1) + bias */
 #define DADD_TUNE_SHALLOW 16 /* tuning: keep one K tile in flight instead of two (A/B measurements) */
 #define DADD_TUNE_NODMA 32   /* tuning: register-staged kernel instead of the LDS-DMA ring kernel */
 #define DADD_TUNE_PERSIST 64 /* tuning: LDS-DMA ring kept running over several output tiles per workgroup */
@@ -61,6 +64,7 @@ int dadd_device_info(int device, int64_t out[4]);
  * reference calls at src/models/unet/unet.py:140-144, src/models/vae/vae.py:88,112 and
  * src/models/attention_processor_routing_gates.py:123,133-137,161-162,183.
  * Contract: (C1+C2) % 64 == 0, C1 % 64 == 0, N % 8 == 0, 16-byte aligned pointers.
+ * tile_n 64 / tile_m 64 select the small LDS-DMA tiles (short GEMMs of the 16x16 / 8x8 maps).
  * splitk > 1 needs `partial` (fp32, splitk*M*N); the slabs are combined by the last-arriving slice of
  * each tile when `counters` is given, else by a finish kernel launched by the same call. */
 typedef struct {
@@ -75,10 +79,13 @@ typedef struct {
   int32_t B, Hi, Wi, C1, C2, Ho, Wo, N;
   int32_t taps, stride, ups, pad;
   int32_t ldo, ldr, ld_rowvec;
-  int32_t splitk, flags, tile_n; /* tile_n: 128 or 160 (0 = choose) */
+  int32_t splitk, flags, tile_n; /* tile_n: 64, 128 or 160 (0 = choose) */
   int32_t tile_m;                /* 64 or 128 (0 = 128): rows of the output tile */
   int32_t* counters;             /* split-K tickets: >= #output tiles ints, zero between launches; with
                                     them the slabs are combined inside the launch (NULL: finish kernel) */
+  const float* ln_c1;            /* DADD_EPI_LNFOLD: N floats (see the flag); replaces nn.LayerNorm + nn.Linear of
+                                    BasicTransformerBlock.norm1/2/3 -> attn1.to_q|k|v / attn2.to_q / ff.net.0.proj */
+  float ln_eps;
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 

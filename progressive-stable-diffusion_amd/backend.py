@@ -103,7 +103,8 @@ class HipBackend:
                                                   mean.numel(), self.s))
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
-              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None):
+              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
+              ln_eps=1e-5):
         """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU)."""
         b, hi, wi, c1 = x.shape
         c2 = 0 if x2 is None else x2.shape[-1]
@@ -120,6 +121,9 @@ class HipBackend:
         d.ld_rowvec = rowvec.stride(0) if rowvec is not None else 0
         d.splitk, d.flags, d.tile_n, d.tile_m = splitk, flags, tile_n, tile_m
         d.counters = _p(counters)
+        d.ln_c1, d.ln_eps = _p(ln_c1), float(ln_eps)
+        if ln_c1 is not None:
+            assert flags & L.EPI_LNFOLD and ln_c1.numel() == n and ln_c1.dtype == torch.float32
         if partial is not None:
             assert partial.numel() >= splitk * b * ho * wo * n
         L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))

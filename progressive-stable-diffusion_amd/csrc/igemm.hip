@@ -30,7 +30,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8;
 }
 
-template <int BM, int BN, bool DEEP>
+template <int BM, int BN, bool DEEP, bool LNF>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   constexpr int WM = BM / 2;       // rows per wave (64 or 32)
   constexpr int MI = WM / 16;      // m-fragments per wave (4 or 2)
@@ -80,6 +80,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
 
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  [[maybe_unused]] float ls1[MI], ls2[MI];   // LNF: row statistics of the folded LayerNorm (igemm_args.h)
+  if constexpr (LNF) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) ls1[i] = ls2[i] = 0.f;
+  }
 
   auto gload = [&](int kt, h8 (&ra)[NA], h8 (&rb)[NB]) {
     const int kk = kt * BK;
@@ -134,6 +139,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
+      if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) ln_acc_pair(xa[i], pr, ls1[i], ls2[i]);
+      }
     }
   };
 
@@ -182,7 +193,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   }
 
   // ---- epilogue (shared with igemm_dma.hip): lane holds out[m][n .. n+3] of the swapped MFMA result
-  igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
+  if constexpr (LNF) {
+    ln_finish<MI>(ls1, ls2, p.K, p.ln_eps);
+    igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, ls1, ls2);
+  } else {
+    igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
+  }
 }
 
 // Finishes a split-K launch: sums the fp32 slabs and applies the (non-GEGLU) epilogue.
@@ -224,23 +240,33 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
   }
 }
 
-template <int BM, int BN, bool DEEP>
-int set_attr() {
+template <int BM, int BN, bool DEEP, bool LNF>
+int set_attr1() {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP, LNF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
 }
-
 template <int BM, int BN, bool DEEP>
-int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
+int set_attr() {
+  const int rc = set_attr1<BM, BN, DEEP, false>();
+  return rc == DADD_OK ? set_attr1<BM, BN, DEEP, true>() : rc;
+}
+
+template <int BM, int BN, bool DEEP, bool LNF>
+int launch1(const IgemmArgs& a, int nsplit, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
   const int mtiles = (a.M + BM - 1) / BM;
   dim3 grid(mtiles * a.ntiles, nsplit);
-  static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + (DEEP ? "true" : "false") + ">";
-  dadd_launch({name.c_str(), dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_kernel<BM, BN, DEEP>, grid, dim3(256), smem, s, a);
+  static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " +
+                                  (DEEP ? "true" : "false") + ", " + (LNF ? "true" : "false") + ">";
+  dadd_launch({name.c_str(), dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_kernel<BM, BN, DEEP, LNF>, grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
+}
+template <int BM, int BN, bool DEEP>
+int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
+  return (a.flags & DADD_EPI_LNFOLD) ? launch1<BM, BN, DEEP, true>(a, nsplit, s) : launch1<BM, BN, DEEP, false>(a, nsplit, s);
 }
 
 template <int BM, int BN>
@@ -279,7 +305,9 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags & (15 | DADD_TUNE_PERSIST);   // epilogue bits + the persistent-ring request
+  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD);   // epilogue bits + the persistent-ring request
+  a.ln_c1 = d->ln_c1;
+  a.ln_eps = d->ln_eps;
   const int Cin = a.C1 + a.C2;
   const bool geglu = (a.flags & DADD_EPI_GEGLU) != 0;
   a.ldo = d->ldo > 0 ? d->ldo : (geglu ? a.N / 2 : a.N);
@@ -302,6 +330,8 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   DADD_REQUIRE(!(a.flags & DADD_EPI_BIAS) || a.bias, "igemm: bias flag without bias");
   DADD_REQUIRE(!(a.flags & DADD_EPI_ROWVEC) || a.rowvec, "igemm: rowvec flag without rowvec");
   DADD_REQUIRE(!(a.flags & DADD_EPI_RESIDUAL) || a.residual, "igemm: residual flag without ptr");
+  DADD_REQUIRE(!(a.flags & DADD_EPI_LNFOLD) || (a.ln_c1 && a.taps == 1 && a.C2 == 0 && d->splitk <= 1 && a.ln_eps > 0.f),
+               "igemm: a folded LayerNorm needs c1, a plain linear over one source (K = C) and no split-K");
   DADD_REQUIRE(a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ld_rowvec % 4 == 0,
                "igemm: leading dimensions must be multiples of 4");
 

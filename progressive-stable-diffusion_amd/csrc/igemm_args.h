@@ -12,6 +12,8 @@ struct IgemmArgs {
   const float* rowvec;
   const half_t* residual;
   int* counters;   // split-K tickets, one per output tile, zero between launches (nullptr: finish kernel)
+  const float* ln_c1;   // DADD_EPI_LNFOLD: c1[n] = sum_k w[n][k] (w already carries the LayerNorm gamma)
+  float ln_eps;
   int B, Hi, Wi, C1, C2, Ho, Wo, N;
   int taps, stride, ups, pad;
   int ldo, ldr, ld_rowvec;
@@ -65,6 +67,37 @@ static inline double dadd_igemm_bytes(const IgemmArgs& a) {
   const double n_out = (a.flags & DADD_EPI_GEGLU) ? a.N / 2 : a.N;
   return 2.0 * ((double)a.B * a.Hi * a.Wi * (a.C1 + a.C2) + (double)a.N * a.K + (double)a.M * n_out +
                 ((a.flags & DADD_EPI_RESIDUAL) ? (double)a.M * a.N : 0.0));
+}
+
+// ---- LayerNorm folded into the consuming linear (DADD_EPI_LNFOLD) -----------------------------------------------
+//   LN(x) W^T + b = rstd_m * (x (gamma o W)^T - mu_m * c1) + (W beta + b),   c1[n] = sum_k gamma_k W[n][k]
+// The caller passes gamma o W as the weight, c1 and the composed bias; the kernel needs mu_m and rstd_m of every
+// row of its tile.  K = C for these linears, so the MFMA waves see whole rows pass through their A fragments: each
+// lane accumulates sum x and sum x^2 of the 8-element pieces it reads anyway (v_dot2_f32_f16: exact products, fp32
+// sums), and two xor-shuffles over the four k-quarters of a fragment finish the row — whose outputs that same lane
+// owns in the swapped-MFMA layout.  No statistics pass, no normalised copy of the activation, no extra launch.
+typedef _Float16 dadd_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ln_acc_pair(const h8& x, int p, float& s1, float& s2) {
+  const dadd_h2 v = {x[2 * p], x[2 * p + 1]};
+  const dadd_h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+  s1 = __builtin_amdgcn_fdot2(v, one, s1, false);
+  s2 = __builtin_amdgcn_fdot2(v, v, s2, false);
+}
+template <int MI>
+__device__ __forceinline__ void ln_finish(float (&s1)[MI], float (&s2)[MI], int K, float eps) {   // -> mu, rstd
+  const float inv = 1.0f / (float)K;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float a = s1[i], q = s2[i];
+    a += __shfl_xor(a, 16, 64);
+    q += __shfl_xor(q, 16, 64);
+    a += __shfl_xor(a, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float mu = a * inv;
+    const float var = fmaxf(q * inv - mu * mu, 0.f);
+    s1[i] = mu;
+    s2[i] = rsqrtf(var + eps);
+  }
 }
 
 int dadd_init_igemm_dma();

@@ -39,7 +39,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Tile BM x BN x 64 with BM in {64, 128}, BN in {64, 128, 160}.  The 64-row tiles exist for the short GEMMs of the
 // 16x16 / 8x8 levels (M = 1024 / 256): they fill the chip without split-K slabs, and two of their workgroups
 // (64 KB of LDS each at 64x64) share a CU, so one's prologue / epilogue hides under the other's K loop.
-template <int BM, int BN, bool UPS, bool PERS>
+// LNF: a LayerNorm folded into this linear (igemm_args.h) — the MFMA waves also accumulate the row statistics.
+template <int BM, int BN, bool UPS, bool PERS, bool LNF>
 __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type exists only in device code; the host
                                       // pass needs just the launch stub of this signature
@@ -295,6 +296,12 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
     for (int j = 0; j < J; ++j)
 #pragma unroll
       for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] float ls1[MI], ls2[MI];          // LNF: per-lane sum x, sum x^2 of rows (lane & 15) + 16 i
+    constexpr int LQ = MI * 4, LPER = (LQ + MI * J - 1) / (MI * J);   // (fragment, register pair) steps per MFMA slot
+    if constexpr (LNF) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) ls1[i] = ls2[i] = 0.f;
+    }
     for (int it = 0; it < nk; ++it) {
       if (started) __builtin_amdgcn_s_barrier();
       started = true;
@@ -311,6 +318,11 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
       for (int k = 0; k < MI * J; ++k) {     // first K half; the second half's fragments stream in behind
         const int jj = k / MI, ii = k % MI;
         acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb0[jj], xa0[ii], acc[jj][ii], 0, 0, 0);
+        if constexpr (LNF) {
+#pragma unroll
+          for (int t2 = 0; t2 < LPER; ++t2)
+            if (k * LPER + t2 < LQ) ln_acc_pair(xa0[(k * LPER + t2) / 4], (k * LPER + t2) % 4, ls1[(k * LPER + t2) / 4], ls2[(k * LPER + t2) / 4]);
+        }
         if (k == 0) wb1[0] = *reinterpret_cast<const h8*>(cb1);
         else if (k <= MI) xa1[k - 1] = *reinterpret_cast<const h8*>(ca + (k - 1) * 2048);
         else if (k < MI + J) wb1[k - MI] = *reinterpret_cast<const h8*>(cb1 + (k - MI) * 2048);
@@ -320,6 +332,11 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
       for (int k = 0; k < MI * J; ++k) {     // second K half; prefetch of tile it+1's first half
         const int jj = k / MI, ii = k % MI;
         acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb1[jj], xa1[ii], acc[jj][ii], 0, 0, 0);
+        if constexpr (LNF) {
+#pragma unroll
+          for (int t2 = 0; t2 < LPER; ++t2)
+            if (k * LPER + t2 < LQ) ln_acc_pair(xa1[(k * LPER + t2) / 4], (k * LPER + t2) % 4, ls1[(k * LPER + t2) / 4], ls2[(k * LPER + t2) / 4]);
+        }
         if (k == 0) wb0[0] = *reinterpret_cast<const h8*>(nb);
         else if (k <= MI) xa0[k - 1] = *reinterpret_cast<const h8*>(na + (k - 1) * 2048);
         else if (k < MI + J) wb0[k - MI] = *reinterpret_cast<const h8*>(nb + (k - MI) * 2048);
@@ -330,7 +347,12 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
     }
     int nt, mt;
     tile_decode(p, tile_first + tl, mt, nt);
-    igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+    if constexpr (LNF) {
+      ln_finish<MI>(ls1, ls2, p.K, p.ln_eps);
+      igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem, ls1, ls2);
+    } else {
+      igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+    }
   }
 #endif
 }
@@ -338,33 +360,49 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
 template <int BM, int BN>
 constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2; }
 
-template <int BM, int BN, bool UPS, bool PERS>
+template <int BM, int BN, bool UPS, bool PERS, bool LNF>
 int set_attr() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, UPS, PERS>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, UPS, PERS, LNF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
   return DADD_OK;
 }
 
 int g_num_cu = 0;
 
-template <int BM, int BN, bool UPS, bool PERS>
-void launch(const char* name, const IgemmArgs& a, dim3 grid, hipStream_t s) {
-  dadd_launch({name, dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_dma_kernel<BM, BN, UPS, PERS>, grid, dim3(512),
+template <int BM, int BN, bool UPS, bool PERS, bool LNF>
+void launch1(const char* name, const IgemmArgs& a, dim3 grid, hipStream_t s) {
+  dadd_launch({name, dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_dma_kernel<BM, BN, UPS, PERS, LNF>, grid, dim3(512),
               smem_bytes<BM, BN>(), s, a);
+}
+// plain linears / convs and (no upsample) their LayerNorm-folded twins
+template <int BM, int BN, bool UPS, bool PERS>
+void launch(const char* name, const char* name_ln, const IgemmArgs& a, dim3 grid, hipStream_t s) {
+  if constexpr (!UPS) {
+    if (a.flags & DADD_EPI_LNFOLD) {
+      launch1<BM, BN, false, PERS, true>(name_ln, a, grid, s);
+      return;
+    }
+  }
+  launch1<BM, BN, UPS, PERS, false>(name, a, grid, s);
+}
+template <int BM, int BN, bool PERS>
+int set_attr2() {
+  int rc = set_attr<BM, BN, false, PERS, false>();
+  return rc == DADD_OK ? set_attr<BM, BN, false, PERS, true>() : rc;
 }
 
 }  // namespace
 
 int dadd_init_igemm_dma() {
-  int rc = set_attr<128, 128, false, true>();
-  if (rc == DADD_OK) rc = set_attr<128, 160, false, true>();
-  if (rc == DADD_OK) rc = set_attr<128, 128, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, 128, true, false>();
-  if (rc == DADD_OK) rc = set_attr<128, 160, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, 160, true, false>();
-  if (rc == DADD_OK) rc = set_attr<64, 64, false, false>();
-  if (rc == DADD_OK) rc = set_attr<64, 128, false, false>();
-  if (rc == DADD_OK) rc = set_attr<64, 160, false, false>();
+  int rc = set_attr2<128, 128, true>();
+  if (rc == DADD_OK) rc = set_attr2<128, 160, true>();
+  if (rc == DADD_OK) rc = set_attr2<128, 128, false>();
+  if (rc == DADD_OK) rc = set_attr2<128, 160, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 128, true, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 160, true, false, false>();
+  if (rc == DADD_OK) rc = set_attr2<64, 64, false>();
+  if (rc == DADD_OK) rc = set_attr2<64, 128, false>();
+  if (rc == DADD_OK) rc = set_attr2<64, 160, false>();
   int dev = 0;
   DADD_HIP(hipGetDevice(&dev));
   DADD_HIP(hipDeviceGetAttribute(&g_num_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -385,23 +423,23 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_m, int tile_n, int nsplit
                "igemm(dma): operand larger than the 2 GiB buffer window");
   if (tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit)) {
     dim3 grid(g_num_cu);
-    if (tile_n == 160) launch<128, 160, false, true>("igemm_dma_kernel<128, 160, false, true>", a, grid, s);
-    else launch<128, 128, false, true>("igemm_dma_kernel<128, 128, false, true>", a, grid, s);
+    if (tile_n == 160) launch<128, 160, false, true>("igemm_dma_kernel<128, 160, false, true, false>", "igemm_dma_kernel<128, 160, false, true, true>", a, grid, s);
+    else launch<128, 128, false, true>("igemm_dma_kernel<128, 128, false, true, false>", "igemm_dma_kernel<128, 128, false, true, true>", a, grid, s);
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }
   dim3 grid(total, nsplit);
   if (tile_m == 64) {
     DADD_REQUIRE(!a.ups, "igemm(dma): the 64-row tiles have no upsample gather");
-    if (tile_n == 160) launch<64, 160, false, false>("igemm_dma_kernel<64, 160, false, false>", a, grid, s);
-    else if (tile_n == 128) launch<64, 128, false, false>("igemm_dma_kernel<64, 128, false, false>", a, grid, s);
-    else launch<64, 64, false, false>("igemm_dma_kernel<64, 64, false, false>", a, grid, s);
+    if (tile_n == 160) launch<64, 160, false, false>("igemm_dma_kernel<64, 160, false, false, false>", "igemm_dma_kernel<64, 160, false, false, true>", a, grid, s);
+    else if (tile_n == 128) launch<64, 128, false, false>("igemm_dma_kernel<64, 128, false, false, false>", "igemm_dma_kernel<64, 128, false, false, true>", a, grid, s);
+    else launch<64, 64, false, false>("igemm_dma_kernel<64, 64, false, false, false>", "igemm_dma_kernel<64, 64, false, false, true>", a, grid, s);
   } else if (tile_n == 160) {
-    if (a.ups) launch<128, 160, true, false>("igemm_dma_kernel<128, 160, true, false>", a, grid, s);
-    else launch<128, 160, false, false>("igemm_dma_kernel<128, 160, false, false>", a, grid, s);
+    if (a.ups) launch<128, 160, true, false>("igemm_dma_kernel<128, 160, true, false, false>", "", a, grid, s);
+    else launch<128, 160, false, false>("igemm_dma_kernel<128, 160, false, false, false>", "igemm_dma_kernel<128, 160, false, false, true>", a, grid, s);
   } else {
-    if (a.ups) launch<128, 128, true, false>("igemm_dma_kernel<128, 128, true, false>", a, grid, s);
-    else launch<128, 128, false, false>("igemm_dma_kernel<128, 128, false, false>", a, grid, s);
+    if (a.ups) launch<128, 128, true, false>("igemm_dma_kernel<128, 128, true, false, false>", "", a, grid, s);
+    else launch<128, 128, false, false>("igemm_dma_kernel<128, 128, false, false, false>", "igemm_dma_kernel<128, 128, false, false, true>", a, grid, s);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

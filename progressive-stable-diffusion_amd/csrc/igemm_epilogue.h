@@ -12,9 +12,11 @@
 #pragma once
 #include "igemm_args.h"
 
+// `ln_mu` / `ln_rs` (MI values each, or nullptr): row mean and 1/std of the folded LayerNorm (igemm_args.h).
 template <int J, int MI, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][MI], int m0, int n0,
-                                               int wm, int wn, int lane, int z, char* smem) {
+                                               int wm, int wn, int lane, int z, char* smem,
+                                               const float* ln_mu = nullptr, const float* ln_rs = nullptr) {
   const int g = lane >> 4, mc = lane & 15;
   const int HoWo = p.Ho * p.Wo;
   if (p.splitk > 1) {
@@ -74,6 +76,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
           const int ng = nh + 32;
           if (ng >= p.N) continue;
           f4 hv = acc[j][i], gv = acc[j + 2][i];
+          if (ln_mu) {
+            hv = ln_rs[i] * (hv - ln_mu[i] * *reinterpret_cast<const f4*>(p.ln_c1 + nh));
+            gv = ln_rs[i] * (gv - ln_mu[i] * *reinterpret_cast<const f4*>(p.ln_c1 + ng));
+          }
           if (p.flags & DADD_EPI_BIAS) {
             hv += *reinterpret_cast<const f4*>(p.bias + nh);
             gv += *reinterpret_cast<const f4*>(p.bias + ng);
@@ -92,6 +98,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
       const int n = n0 + wn * WN + j * 16 + g * 4;
       if (n >= p.N) continue;
       f4 v = acc[j][i];
+      if (ln_mu) v = ln_rs[i] * (v - ln_mu[i] * *reinterpret_cast<const f4*>(p.ln_c1 + n));
       if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
       if (p.flags & DADD_EPI_ROWVEC)
         v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);

@@ -77,6 +77,21 @@ def geglu_interleave(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, to
     return w[src].contiguous(), b[src].contiguous()
 
 
+def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm folded into the linear that consumes it (csrc/igemm_args.h, DADD_EPI_LNFOLD):
+    LN(x) W^T + b = rstd (x (gamma o W)^T - mu c1) + (W beta + b).  Returns (gamma o W in fp16, c1, composed bias);
+    c1 sums the ROUNDED weights, so that the mean term cancels exactly against what the MFMAs accumulate."""
+    w, gamma, beta = w.double(), gamma.double(), beta.double()
+    w16 = (w * gamma[None, :]).to(F16)
+    bias = w @ beta + (b.double() if b is not None else 0.0)
+    return w16, w16.double().sum(dim=1).float(), bias.float()
+
+
+# LayerNorm folded into the consuming linear (qkv, attn2.to_q, GEGLU projection) instead of a LayerNorm launch and a
+# normalised copy of the hidden states per transformer block.  Module-level switch for A/B measurements and tests.
+LN_FOLD = True
+
+
 def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False,
                   residual: bool = True) -> Tuple[int, int, int]:
     """(tile_m, splitk, tune_flags) for one implicit GEMM with 128- or 160-column tiles, from measurements over
@@ -210,18 +225,21 @@ class _Plan:
 
     # ---- recorded building blocks -----------------------------------------------------------
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
-             stride=1, ups=0, pad=1, flags=0):
+             stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5):
         out = self.pool.get(out_shape)
         n = w.shape[0]
         m = out_shape[0] * out_shape[1] * out_shape[2]
         tile_m, tile_n, sk, tune = plan_tiling(m, n, w.shape[1], taps, bool(flags & L.EPI_GEGLU), residual is not None,
                                                ups, stride)
+        if ln_c1 is not None:
+            sk = 1                      # the row statistics come from whole rows of A: no K slices
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
-            | (L.EPI_RESIDUAL if residual is not None else 0) | tune
+            | (L.EPI_RESIDUAL if residual is not None else 0) | (L.EPI_LNFOLD if ln_c1 is not None else 0) | tune
+        kw = dict(ln_c1=ln_c1, ln_eps=ln_eps) if ln_c1 is not None else {}
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
                  taps=taps, stride=stride, ups=ups, pad=pad, flags=f, splitk=sk, partial=partial,
-                 tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None)  # None: finish kernel
+                 tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None, **kw)  # None: finish kernel
         self.pool.put(partial)
         return out
 
@@ -355,20 +373,43 @@ class UNetPlan(_Plan):
             self.pool.put(res)
         return out
 
+    def _ln_linear(self, tb, norm, name, wkey_list, bias_key=None, geglu=False):
+        """Device tensors (w16, c1, bias) of ``norm`` folded into the linear(s) ``wkey_list`` (rows concatenated)."""
+        u = self.prefix
+
+        def make():
+            w = torch.cat([self.sd[u + tb + k] for k in wkey_list])
+            b = self.sd[u + tb + bias_key] if bias_key else None
+            w16, c1, bias = fold_layernorm(w, b, self.sd[u + tb + norm + ".weight"], self.sd[u + tb + norm + ".bias"])
+            if geglu:               # row order of the fused GEGLU epilogue; c1 / bias follow their rows
+                idx = geglu_interleave(torch.arange(w16.shape[0])[:, None].float(), torch.zeros(w16.shape[0]))[0][:, 0].long()
+                w16, c1, bias = w16[idx], c1[idx], bias[idx]
+            return self.dev(w16.contiguous()), self.dev(c1.contiguous()), self.dev(bias.contiguous())
+        t = self.cached((u + tb, "lnfold", name), make)
+        if self.wcache is not None:
+            self.keep += list(t)
+        return t
+
     def _transformer(self, site, x):
         b, h, w_, c = x.shape
         shp = (b, h, w_, c)
         tb = site + ".transformer_blocks.0"
+        fold = LN_FOLD
         g = self.gn(x, None, self.f(site + ".norm.weight"), self.f(site + ".norm.bias"), 1e-6, 0)
         hs = self.conv(g, self.w(site + ".proj_in.weight"), shp, bias=self.f(site + ".proj_in.bias"),
                        taps=1, pad=0)
         self.pool.put(g)
-        ln = self.pool.get(shp)
+        need_ln = (not fold) or site in self.a2        # the fused attn2 kernel reads a normalised copy
+        ln = self.pool.get(shp) if need_ln else None
         # attn1 (self)
-        self.rec(self.be.layernorm, hs, self.f(tb + ".norm1.weight"), self.f(tb + ".norm1.bias"), ln)
-        wqkv = self.cached((self.prefix + tb, "qkv"), lambda: self.dev(
-            torch.cat([self.sd[self.prefix + tb + f".attn1.to_{n}.weight"] for n in "qkv"]), F16))
-        qkv = self.conv(ln, wqkv, (b, h, w_, 3 * c), taps=1, pad=0)
+        if fold:
+            wqkv, c1, bqkv = self._ln_linear(tb, ".norm1", "qkv", [f".attn1.to_{n}.weight" for n in "qkv"])
+            qkv = self.conv(hs, wqkv, (b, h, w_, 3 * c), bias=bqkv, taps=1, pad=0, ln_c1=c1)
+        else:
+            self.rec(self.be.layernorm, hs, self.f(tb + ".norm1.weight"), self.f(tb + ".norm1.bias"), ln)
+            wqkv = self.cached((self.prefix + tb, "qkv"), lambda: self.dev(
+                torch.cat([self.sd[self.prefix + tb + f".attn1.to_{n}.weight"] for n in "qkv"]), F16))
+            qkv = self.conv(ln, wqkv, (b, h, w_, 3 * c), taps=1, pad=0)
         att = self.pool.get(shp)
         self.rec(self.be.self_attn, qkv.view(b, h * w_, 3 * c), att.view(b, h * w_, c), HEADS)
         self.pool.put(qkv)
@@ -376,29 +417,39 @@ class UNetPlan(_Plan):
                        bias=self.f(tb + ".attn1.to_out.0.bias"), residual=hs, taps=1, pad=0)
         self.pool.put(hs)
         # attn2 (DADD cross-attention)
-        self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
         if site in self.a2:          # one kernel: x (W_q K^T) -> 24 softmaxes -> P (V W_o^T) + bias + residual
+            self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
             st = self.a2[site]
             h3 = self.pool.get(shp)
             self.rec(self.be.attn2_fused, ln.view(b, h * w_, c), st["mcat"], st["vw"],
                      self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c))
         else:
-            q = self.conv(ln, self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
+            if fold:
+                wq, c1, bq = self._ln_linear(tb, ".norm2", "to_q", [".attn2.to_q.weight"])
+                q = self.conv(h2, wq, shp, bias=bq, taps=1, pad=0, ln_c1=c1)
+            else:
+                self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
+                q = self.conv(ln, self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
             self.rec(self._xattn, site, q.view(b, h * w_, c), att.view(b, h * w_, c))
             self.pool.put(q)
             h3 = self.conv(att, self.w(tb + ".attn2.to_out.0.weight"), shp,
                            bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0)
         self.pool.put(h2, att)
         # GEGLU feed-forward
-        self.rec(self.be.layernorm, h3, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"), ln)
-        def _geglu():
-            wf, bf = geglu_interleave(self.sd[self.prefix + tb + ".ff.net.0.proj.weight"],
-                                      self.sd[self.prefix + tb + ".ff.net.0.proj.bias"])
-            return self.dev(wf, F16), self.dev(bf.float())
-        wf, bf = self.cached((self.prefix + tb, "geglu"), _geglu)
-        if self.wcache is not None:
-            self.keep += [wf, bf]
-        ff = self.conv(ln, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU)
+        if fold:
+            wf, c1, bf = self._ln_linear(tb, ".norm3", "geglu", [".ff.net.0.proj.weight"], ".ff.net.0.proj.bias", geglu=True)
+            ff = self.conv(h3, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU, ln_c1=c1)
+        else:
+            self.rec(self.be.layernorm, h3, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"), ln)
+
+            def _geglu():
+                wf, bf = geglu_interleave(self.sd[self.prefix + tb + ".ff.net.0.proj.weight"],
+                                          self.sd[self.prefix + tb + ".ff.net.0.proj.bias"])
+                return self.dev(wf, F16), self.dev(bf.float())
+            wf, bf = self.cached((self.prefix + tb, "geglu"), _geglu)
+            if self.wcache is not None:
+                self.keep += [wf, bf]
+            ff = self.conv(ln, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU)
         self.pool.put(ln)
         h4 = self.conv(ff, self.w(tb + ".ff.net.2.weight"), shp, bias=self.f(tb + ".ff.net.2.bias"),
                        residual=h3, taps=1, pad=0)

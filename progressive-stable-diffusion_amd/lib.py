@@ -16,6 +16,7 @@ SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "attn2_fused.hip", "no
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+EPI_LNFOLD = 128
 TUNE_SHALLOW, TUNE_NODMA, TUNE_PERSIST = 16, 32, 64
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
 GN_MAX_CHUNKS = 256
@@ -28,7 +29,7 @@ class IgemmDesc(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "x2", "w", "out", "partial", "bias", "rowvec", "residual")] + \
                [(n, i32) for n in ("B", "Hi", "Wi", "C1", "C2", "Ho", "Wo", "N", "taps", "stride",
                                    "ups", "pad", "ldo", "ldr", "ld_rowvec", "splitk", "flags",
-                                   "tile_n", "tile_m")] + [("counters", vp)]
+                                   "tile_n", "tile_m")] + [("counters", vp), ("ln_c1", vp), ("ln_eps", f32)]
 
 
 # name -> (restype, argtypes); every symbol include/dadd_hip.h declares

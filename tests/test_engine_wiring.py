@@ -82,8 +82,10 @@ def test_splitk_heuristic():
         assert tm in (64, 128) and 1 <= s <= 32 and (k // 64) // s >= 4
 
 
-@pytest.mark.parametrize("lam", [0.0, 3.0])
-def test_unet_plan_matches_oracle(unet_sd, lam):
+@pytest.mark.parametrize("lam,fold", [(0.0, True), (3.0, True), (3.0, False)])
+def test_unet_plan_matches_oracle(unet_sd, lam, fold, monkeypatch):
+    """fold: LayerNorm folded into the consuming linears (48 launches less per step) or as its own op."""
+    monkeypatch.setattr(E, "LN_FOLD", fold)
     torch.manual_seed(1)
     b, s = 2, 8
     plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
@@ -94,7 +96,8 @@ def test_unet_plan_matches_oracle(unet_sd, lam):
         got = plan.forward(x, t, cond, lam=lam)
     assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item())
     # every pooled buffer is handed back exactly once: no leak of plan-time buffers
-    assert len(plan.ops) > 300
+    n_ln = sum(1 for fn, _, _ in plan.ops if getattr(fn, "__name__", "") == "layernorm")
+    assert n_ln == (len(plan.a2) if fold else 48) and len(plan.ops) > 250     # fused-attn2 sites keep LayerNorm 2
 
 
 def test_unet_plan_baseline_mode(full_sd):

@@ -114,6 +114,47 @@ def test_igemm_dma_tile_shapes(hip, tile_m, tile_n, case):
     close(o, o_ref, 3e-3, 2e-3, f"dma tile {tile_m}x{tile_n} {case}")
 
 
+@pytest.mark.parametrize("tile_m,tile_n,tune", [(64, 64, 0), (64, 128, 0), (64, 160, 0), (128, 128, 0), (128, 160, 0),
+                                                (128, 160, 64), (64, 160, 32), (128, 128, 32), (64, 128, 48)])
+@pytest.mark.parametrize("geglu", [False, True])
+def test_igemm_layernorm_fold(hip, tile_m, tile_n, tune, geglu):
+    """DADD_EPI_LNFOLD on every kernel that can carry it (LDS-DMA tiles, persistent ring = tune 64, register-staged
+    = tune 32 / 48): out = rstd (x (gamma o W)^T - mu c1) + (W beta + b) with mu / rstd accumulated from the A
+    fragments, against LayerNorm -> Linear in fp32 torch.  Rows with a large common offset (|mean| = 3 sigma)
+    exercise the cancellation of the mean term.  Tolerance: one fp16 rounding of the result + fp16 weights."""
+    from progressive_stable_diffusion_amd import engine as E
+    from progressive_stable_diffusion_amd import lib as L
+    import torch.nn.functional as Fn
+    if geglu and tile_n != 128:
+        pytest.skip("the GEGLU epilogue runs on 128-column tiles")
+    m, k = (1200 if tune != 64 else 40000), 640
+    n = 1024 if tile_n != 160 else 960
+    if geglu:
+        n = 1024
+    g = torch.Generator().manual_seed(80)
+    x = (torch.randn(1, m, 1, k, generator=g) + 3.0 * torch.randn(1, m, 1, 1, generator=g)).to(F16)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g) * 0.1
+    gamma, beta = 1.0 + 0.2 * torch.randn(k, generator=g), 0.2 * torch.randn(k, generator=g)
+    ref = Fn.linear(Fn.layer_norm(x.float(), (k,), gamma, beta, 1e-5), w.to(F16).float(), b)
+    if geglu:
+        hid, gate = ref.chunk(2, dim=-1)
+        ref = hid * Fn.gelu(gate)
+    w16, c1, bias = E.fold_layernorm(w, b, gamma, beta)
+    if geglu:
+        idx = E.geglu_interleave(torch.arange(n)[:, None].float(), torch.zeros(n))[0][:, 0].long()
+        w16, c1, bias = w16[idx], c1[idx], bias[idx]
+    o = hip.zeros((1, m, 1, n // 2 if geglu else n), F16)
+    hip.igemm(dev(hip, x), dev(hip, w16.contiguous()), o, bias=dev(hip, bias.contiguous()),
+              flags=L.EPI_BIAS | L.EPI_LNFOLD | (L.EPI_GEGLU if geglu else 0) | tune, tile_m=tile_m, tile_n=tile_n,
+              ln_c1=dev(hip, c1.contiguous()))
+    hip.synchronize()
+    close(o, ref, 6e-3, 6e-3, f"ln fold {tile_m}x{tile_n} tune{tune} geglu{geglu}")
+    with pytest.raises(ValueError):       # a folded LayerNorm needs whole rows of A: no split-K
+        hip.igemm(dev(hip, x), dev(hip, w16.contiguous()), o, flags=L.EPI_LNFOLD, splitk=2, partial=hip.zeros((2 * m * n,), F32),
+                  ln_c1=dev(hip, c1.contiguous()))
+
+
 @pytest.mark.parametrize("taps", [1, 9])
 def test_igemm_skip_concat(hip, taps):
     b, h, c1, c2, n = 2, 8, 640, 320, 640

@@ -479,3 +479,49 @@ def test_main_cli_end_to_end(full_sd, tmp_path):
     a = np.asarray(Image.open(out / "mes_0.00_00.png"))
     b = np.asarray(Image.open(out / "mes_3.00_02.png"))
     assert a.shape == (64, 64, 3) and np.abs(a.astype(int) - b.astype(int)).max() > 0
+
+
+@pytest.mark.parametrize("image,batch", [(128, 2), (256, 1)])
+def test_vae_encode_matches_oracle(hip, image, batch):
+    """``SDVAE.encode`` on the HIP kernels (asymmetric-pad stride-2 convs, mid attention d = 512, quant_conv composed
+    into conv_out) + the reparameterised sample with injected noise vs ``oracle.sd_vae`` (SURVEY.md §8 a15 / north_star
+    'VAE encode').  Tolerance: moments 2e-2 of their max (fp16 storage through 24 convs), sample 2e-2."""
+    from oracle.sd_vae import vae_encode_moments, vae_encode_sample
+    from progressive_stable_diffusion_amd import weights as W
+    from progressive_stable_diffusion_amd.engine import VaeEncoderPlan
+    sd = W.init_state_dict(W.vae_shapes(decoder=False), 0)
+    s = image // 8
+    plan = VaeEncoderPlan(hip, sd, batch, s)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(batch, 3, image, image, generator=g) * 2 - 1
+    noise = torch.randn(batch, 4, s, s, generator=g)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        mean, logvar = vae_encode_moments(sd, x)
+        ref = vae_encode_sample(sd, x, noise) * 0.18215
+    hip.copy_(plan.img_in, x.to(DEV))
+    plan.run()
+    out = hip.zeros((batch, 4, s, s), F32)
+    hip.gaussian_sample(plan.mean, plan.logvar, noise.to(DEV), out, 0.18215)
+    hip.synchronize()
+    em = (plan.mean.cpu() - mean).abs().max().item() / max(1.0, mean.abs().max().item())
+    el = (plan.logvar.cpu() - logvar).abs().max().item() / max(1.0, logvar.abs().max().item())
+    es = (out.cpu() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print(f"vae encode {image}: mean {em:.3e} logvar {el:.3e} sample {es:.3e}")
+    assert em < 2e-2 and el < 2e-2 and es < 2e-2
+
+
+def test_module_vae_encode_on_device(full_sd):
+    """``module.vae.encode(x).latent_dist.sample() * latent_scale`` (diffusion_module_ip.py:410-411) and the
+    encode -> decode round trip through both plans (property: shapes, ranges, determinism of mode())."""
+    from progressive_stable_diffusion_amd import weights as W
+    sd = dict(full_sd)
+    sd.update(W.init_state_dict(W.vae_shapes(decoder=False), 0))
+    mod = _module(sd, 128, 2, clip_config=None)
+    x = (torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(DEV)
+    dist = mod.vae.encode(x).latent_dist
+    z = dist.sample() * mod.diff_cfg.latent_scale
+    assert z.shape == (2, 4, 16, 16) and torch.isfinite(z).all()
+    assert torch.equal(mod.vae.encode(x).latent_dist.mode(), dist.mean)
+    img = mod.vae.decode(dist.mode()).sample
+    assert img.shape == (2, 3, 128, 128) and float(img.min()) >= -1.0 and float(img.max()) <= 1.0

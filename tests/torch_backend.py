@@ -94,7 +94,8 @@ class TorchRefBackend:
         out.copy_((mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise) * scale)
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
-              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None):
+              ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
+              ln_eps=1e-5):
         self.launches += 1
         xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
         b, hi, wi, cin = xin.shape
@@ -114,6 +115,10 @@ class TorchRefBackend:
             y = F.conv2d(xn, wt, None, stride=stride, padding=pad)
         assert y.shape[2] == ho and y.shape[3] == wo, (y.shape, out.shape)
         y = y.permute(0, 2, 3, 1)
+        if flags & 128:                 # EPI_LNFOLD: rstd * (x (gamma o W)^T - mu * c1), statistics of the fp16 rows
+            mu = xin.mean(dim=-1, keepdim=True)
+            var = (xin * xin).mean(dim=-1, keepdim=True) - mu * mu
+            y = torch.rsqrt(var.clamp_min(0.0) + ln_eps) * (y - mu * ln_c1.float())
         flags &= 15                     # tuning bits (16, 32) do not change the math
         if flags & EPI_BIAS:
             y = y + bias.float()
