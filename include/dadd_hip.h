@@ -137,11 +137,15 @@ int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, i
  * SPLIT (T=48): z = anat_gate*softmax(q K_anat^T/sqrt d) V_anat          tokens [16,32), to_k/to_v
  *                 + dis_gate *softmax(q K_dis^T /sqrt d) V_dis           tokens [0,16),  to_*_dis
  *                 + lambda   *softmax(q K_dlt^T /sqrt d) V_dlt (iff lambda != 0)  tokens [32,48)
- * three independent softmaxes; gates are read from device memory (gates[0]=anat, gates[1]=dis).
+ * three independent softmaxes; gates are read from device memory (gates[0]=anat, gates[1]=dis), and so is
+ * lambda when `lambda_dev` is non-null (it then overrides `lambda`): the reference reads `delta_scale` per call
+ * (routing_gates.py:160), so one captured graph must serve a whole lambda sweep; lambda == 0 skips the delta
+ * pathway inside the kernel (its tokens are never read), as :160,177-178 does.
  * Replaces SplitInjectionAttentionProcessor.__call__ lines 142-181 and
  * OrdinalIPAttnProcessor2_0.__call__ lines 92-122 (src/models/attention_processor_*.py). */
 int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* gates, float lambda,
-                       int mode, int B, int N, int heads, int d, int T, int ld_kv, void* stream);
+                       const float* lambda_dev, int mode, int B, int N, int heads, int d, int T, int ld_kv,
+                       void* stream);
 
 /* The whole attn2 block of the routing-gates processor as one launch.  x: LayerNorm output [B*HW][C];
  * mcat [B][384][C]: row (h*3+p)*16+t = log2(e)/sqrt(d) * K_p[b,t,h,:] . W_q[h*d:(h+1)*d, :]   (h < 8 heads,
@@ -167,9 +171,9 @@ int dadd_begin_step(const float* table, float* cur_rows, int B, int ncols, const
 /* DDIM update (eta = 0), op-for-op as inference_pipeline_ip.py:430-456:
  * eps = eps_u + g*(eps_c-eps_u) when eps_u != NULL; x0 = clamp((x - c1*eps)/c0, -4, 4);
  * x = last ? x0 : c2*x0 + c3*eps   with coef = {sqrt(ab_t), sqrt(1-ab_t), sqrt(ab_prev),
- * sqrt(1-ab_prev)} and last encoded as c2 < 0. */
+ * sqrt(1-ab_prev)} and last encoded as c2 < 0.  `guidance_dev` (device float, optional) overrides `guidance`. */
 int dadd_ddim_update_f32(float* x, const float* eps_c, const float* eps_u, float guidance,
-                         const float* coef, int64_t n, void* stream);
+                         const float* guidance_dev, const float* coef, int64_t n, void* stream);
 
 /* ---- hipGraph capture of the step loop ----------------------------------------------------- */
 int dadd_graph_begin(void* stream);

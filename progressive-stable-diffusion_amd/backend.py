@@ -151,9 +151,10 @@ class HipBackend:
         L.check(self.lib.dadd_self_attn_f16(base, base + 2 * c, base + 4 * c, _p(out), b, n, heads,
                                             c // heads, c3, out.stride(-2), self.s))
 
-    def tri_xattn(self, q, kv, out, gates, lam, mode, heads):
+    def tri_xattn(self, q, kv, out, gates, lam, mode, heads, lam_dev=None):
+        """``lam_dev`` (device float32[1]) overrides ``lam``: lambda is then a device-side parameter."""
         b, n, c = q.shape
-        L.check(self.lib.dadd_tri_xattn_f16(_p(q), _p(kv), _p(out), _p(gates), float(lam), int(mode),
+        L.check(self.lib.dadd_tri_xattn_f16(_p(q), _p(kv), _p(out), _p(gates), float(lam), _p(lam_dev), int(mode),
                                             b, n, heads, c // heads, kv.shape[1], kv.stride(1),
                                             self.s))
 
@@ -179,9 +180,9 @@ class HipBackend:
         L.check(self.lib.dadd_begin_step(_p(table), _p(cur_rows), cur_rows.shape[0], table.shape[1],
                                          _p(coef), _p(cur_coef), _p(step), self.s))
 
-    def ddim_update(self, x, eps_c, eps_u, guidance, coef):
-        L.check(self.lib.dadd_ddim_update_f32(_p(x), _p(eps_c), _p(eps_u), float(guidance), _p(coef),
-                                              x.numel(), self.s))
+    def ddim_update(self, x, eps_c, eps_u, guidance, coef, guidance_dev=None):
+        L.check(self.lib.dadd_ddim_update_f32(_p(x), _p(eps_c), _p(eps_u), float(guidance), _p(guidance_dev),
+                                              _p(coef), x.numel(), self.s))
 
     # ------------------------------------------------------------------ graphs / profiling
     def graph_begin(self):

@@ -346,6 +346,7 @@ struct XattnArgs {
   const half_t* kv;
   half_t* out;
   const float* gates;
+  const float* lambda_dev;   // lambda read from device memory when non-null (one captured graph serves a lambda sweep)
   float lambda;
   int B, N, H, T, ldkv, C;
   float scale_log2;
@@ -364,6 +365,10 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
   const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
+  // lambda: by value, or from device memory (then NF = 3 is launched and lambda == 0 skips the delta pathway here,
+  // exactly as attention_processor_routing_gates.py:160,177-178 does: its tokens are never read, NaN cannot leak)
+  const float lam = p.lambda_dev ? *p.lambda_dev : p.lambda;
+  const bool use_delta = JOINT || NF < 3 || lam != 0.f;      // wave-uniform
   // fragment descriptors (wave-uniform)
   int tb[NF], kcol[NF], vcol[NF];
   float wgt[NF];
@@ -373,13 +378,14 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
   } else {
     tb[0] = 16; kcol[0] = 0;       vcol[0] = p.C;     wgt[0] = p.gates[0];  // anatomy
     tb[1] = 0;  kcol[1] = 2 * p.C; vcol[1] = 3 * p.C; wgt[1] = p.gates[1];  // disease
-    if (NF > 2) { tb[NF - 1] = 32; kcol[NF - 1] = 2 * p.C; vcol[NF - 1] = 3 * p.C; wgt[NF - 1] = p.lambda; }
+    if (NF > 2) { tb[NF - 1] = 32; kcol[NF - 1] = 2 * p.C; vcol[NF - 1] = 3 * p.C; wgt[NF - 1] = lam; }
   }
 
   // V rows -> LDS (row f*16 + key), rest zero so that empty key slots contribute exactly 0
   for (int i = t; i < 64 * VLD / 8; i += 256) *reinterpret_cast<h8*>(Vs + i * 8) = zero8;
   __syncthreads();
-  for (int idx = t; idx < NF * 16 * DC; idx += 256) {
+  const int nf_live = use_delta ? NF : NF - 1;
+  for (int idx = t; idx < nf_live * 16 * DC; idx += 256) {
     const int row = idx / DC, ch = idx - row * DC;
     const int f = row >> 4, key = row & 15;
     const size_t off = ((size_t)b * p.T + tb[f] + key) * p.ldkv + vcol[f] + h * DR + ch * 8;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int dc = 32 * s + 8 * g;
-      kA[f][s] = (dc < DR) ? *reinterpret_cast<const h8*>(kp + dc) : zero8;
+      kA[f][s] = (dc < DR && f < nf_live) ? *reinterpret_cast<const h8*>(kp + dc) : zero8;
     }
   }
   h8 vA[DF][KB];
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const float w = wgt[f] / sm[f];
+      const float w = (f < nf_live) ? wgt[f] / sm[f] : 0.f;    // skipped pathway: P = 0 against V rows that stayed 0
 #pragma unroll
       for (int r = 0; r < 4; ++r) sacc[f][r] *= w;
     }
@@ -528,7 +534,7 @@ int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
   const double bytes = tok * c * 4.0;
   if (mode == DADD_XATTN_BASELINE)
     dadd_launch({n2t.c_str(), 4.0 * tok * 32 * c, bytes}, xattn_kernel<DR, 2, true>, grid, dim3(256), 0, s, a);
-  else if (a.lambda != 0.0f)
+  else if (a.lambda_dev != nullptr || a.lambda != 0.0f)
     dadd_launch({n3f.c_str(), 4.0 * tok * 48 * c, bytes}, xattn_kernel<DR, 3, false>, grid, dim3(256), 0, s, a);
   else
     dadd_launch({n2f.c_str(), 4.0 * tok * 32 * c, bytes}, xattn_kernel<DR, 2, false>, grid, dim3(256), 0, s, a);
@@ -577,8 +583,8 @@ extern "C" int dadd_self_attn_f16(const void* q, const void* k, const void* v, v
 }
 
 extern "C" int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* gates,
-                                  float lambda, int mode, int B, int N, int heads, int d, int T,
-                                  int ld_kv, void* stream) {
+                                  float lambda, const float* lambda_dev, int mode, int B, int N, int heads, int d,
+                                  int T, int ld_kv, void* stream) {
   DADD_REQUIRE(q && kv && out, "tri_xattn: null pointer");
   DADD_REQUIRE(mode == DADD_XATTN_SPLIT || mode == DADD_XATTN_BASELINE, "tri_xattn: bad mode");
   const int C = heads * d;
@@ -597,6 +603,7 @@ extern "C" int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, cons
   a.out = static_cast<half_t*>(out);
   a.gates = gates;
   a.lambda = lambda;
+  a.lambda_dev = (mode == DADD_XATTN_SPLIT) ? lambda_dev : nullptr;
   a.B = B; a.N = N; a.H = heads; a.T = T; a.ldkv = ld_kv; a.C = C;
   a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
   hipStream_t s = static_cast<hipStream_t>(stream);

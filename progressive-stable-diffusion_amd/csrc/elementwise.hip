@@ -197,9 +197,11 @@ __global__ __launch_bounds__(1024) void begin_step_kernel(const float* __restric
 
 // Every operation is an individually rounded fp32 op in the reference's order (no FMA contraction).
 __global__ __launch_bounds__(256) void ddim_kernel(float* __restrict__ x, const float* __restrict__ ec,
-                                                   const float* __restrict__ eu, float g,
+                                                   const float* __restrict__ eu, float g_val,
+                                                   const float* __restrict__ g_dev,
                                                    const float* __restrict__ coef, int64_t n) {
 #pragma clang fp contract(off)  // __fmul_rn/__fsub_rn are plain * and - to the optimiser: forbid FMA fusion
+  const float g = g_dev ? *g_dev : g_val;
   const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float e = ec[i];
@@ -320,12 +322,12 @@ extern "C" int dadd_begin_step(const float* table, float* cur_rows, int B, int n
 }
 
 extern "C" int dadd_ddim_update_f32(float* x, const float* eps_c, const float* eps_u, float guidance,
-                                    const float* coef, int64_t n, void* stream) {
+                                    const float* guidance_dev, const float* coef, int64_t n, void* stream) {
   DADD_REQUIRE(x && eps_c && coef && n > 0, "ddim_update: bad arguments");
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   dadd_launch({"ddim_kernel", 0.0, (double)n * (eps_u ? 16.0 : 12.0)}, ddim_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     eps_c, eps_u, guidance, coef, n);
+                     eps_c, eps_u, guidance, guidance_dev, coef, n);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

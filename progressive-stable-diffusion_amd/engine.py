@@ -263,6 +263,9 @@ class UNetPlan(_Plan):
         self.prefix = prefix + "."
         self.sd = sd
         self.lam = 0.0
+        # device-side scalars read by the kernels of a captured step: [0] = lambda (delta steering), [1] = CFG scale
+        self.params = be.zeros((2,), F32)
+        self.params_dev = False      # True while a DdimLoop drives the plan: kernels take lambda from `params`
         self.gn_ws = be.empty((batch * L.GN_MAX_CHUNKS * GROUPS * 2,), F32)
         u = self.prefix
         # ---- time path: linear_1, linear_2, all 22 time_emb_proj concatenated
@@ -462,7 +465,8 @@ class UNetPlan(_Plan):
     def _xattn(self, site, q, out):
         mode = L.XATTN_SPLIT if self.gates_mode else L.XATTN_BASELINE
         kv = self.kv[site][self.kv_slot]
-        self.be.tri_xattn(q, kv.view(self.B, self.T, -1), out, self.gates[site], self.lam, mode, HEADS)
+        self.be.tri_xattn(q, kv.view(self.B, self.T, -1), out, self.gates[site], self.lam, mode, HEADS,
+                          lam_dev=self.params[0:1] if (self.params_dev and self.gates_mode) else None)
 
     def _emit_eps(self, x, w, bias):
         self.be.conv_cout4(x, w, bias, self.eps_out[self.kv_slot], 0)
@@ -557,6 +561,9 @@ class UNetPlan(_Plan):
                 scale = math.log2(math.e) / math.sqrt(d)
                 m = torch.stack([torch.einsum("bthd,hdc->bhtc", k, wq) for k in ks], dim=2) * scale   # b h p t c
                 v = torch.stack([torch.einsum("nhd,bthd->bnht", wo, x) * gg for x, gg in zip(vs, gp)], dim=3)  # b n h p t
+                if float(lam) == 0.0:      # routing_gates.py:160,177-178: the delta pathway is skipped, not scaled —
+                    m[:, :, 2] = 0.0       # zero scores and zero values: garbage (NaN) delta tokens cannot leak
+                    v[:, :, :, 2] = 0.0
                 st["mcat"].copy_(m.reshape(B, 384, c))
                 st["vw"].copy_(v.reshape(B, c, 384))
         self._a2_dirty, self._a2_lam = False, float(lam)
@@ -787,28 +794,39 @@ class DdimLoop:
         self.u.time_rows(self.be.to_device(ts), self.table[:n])
         self.nsteps = n
 
+    def set_params(self, lam: float, guidance: float):
+        """lambda and the CFG scale live in device memory (``unet.params``): the captured step reads them there, so
+        ONE graph per (cfg on/off) serves every (lambda, guidance) — the reference reads ``delta_scale`` per call
+        (attention_processor_routing_gates.py:160).  The fused attn2 sites fold lambda into their step-invariant
+        conditioning (``prepare_attn2``), which is device memory too."""
+        self.be.copy_(self.u.params, torch.tensor([float(lam), float(guidance)], dtype=F32))
+        self.u.prepare_attn2(lam)
+
     def _one_step(self, lam: float, do_cfg: bool, guidance: float):
         u = self.u
-        u.prepare_attn2(lam)          # a no-op unless the conditioning or lambda changed since the last call
-        self.be.begin_step(self.table, u.temb_rows, self.coef, self.cur_coef, self.step)
-        u.run_slot(0, lam)
-        if do_cfg:
-            u.run_slot(1, lam)
-        self.be.ddim_update(u.lat_in, u.eps_out[0], u.eps_out[1] if do_cfg else None, guidance,
-                            self.cur_coef)
+        u.params_dev = True
+        try:
+            self.be.begin_step(self.table, u.temb_rows, self.coef, self.cur_coef, self.step)
+            u.run_slot(0, lam)
+            if do_cfg:
+                u.run_slot(1, lam)
+            self.be.ddim_update(u.lat_in, u.eps_out[0], u.eps_out[1] if do_cfg else None, guidance,
+                                self.cur_coef, guidance_dev=u.params[1:2])
+        finally:
+            u.params_dev = False
 
     def run(self, lam: float, do_cfg: bool = False, guidance: float = 1.0, use_graph: bool = True,
             trace: Optional[list] = None):
         """Runs all prepared steps in place on ``unet.lat_in``."""
         self.be.zero_(self.step)
-        self.u.prepare_attn2(lam)
+        self.set_params(lam, guidance)
         if trace is not None or not use_graph:
             for _ in range(self.nsteps):
                 self._one_step(lam, do_cfg, guidance)
                 if trace is not None:
                     trace.append((self.be.clone(self.u.eps_out[0]), self.be.clone(self.u.lat_in)))
             return
-        key = (float(lam), bool(do_cfg), float(guidance))
+        key = bool(do_cfg)
         g = self.graphs.get(key)
         if g is None:
             self.be.synchronize()

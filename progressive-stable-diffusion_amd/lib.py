@@ -51,12 +51,12 @@ PROTOTYPES = {
     "dadd_self_attn_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, vp]),
     "dadd_attn2_fused_f16": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "dadd_tri_xattn_f16": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "dadd_tri_xattn_f16": (C.c_int, [vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
     "dadd_timestep_features_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "dadd_linear_rows_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_begin_step": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
-    "dadd_ddim_update_f32": (C.c_int, [vp, vp, vp, f32, vp, i64, vp]),
+    "dadd_ddim_update_f32": (C.c_int, [vp, vp, vp, f32, vp, vp, i64, vp]),
     "dadd_graph_begin": (C.c_int, [vp]),
     "dadd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "dadd_graph_launch": (C.c_int, [vp, vp]),

@@ -33,10 +33,22 @@ def test_library_exports_every_declared_symbol():
     assert handle.dadd_version() == 100
 
 
-def test_igemm_desc_layout_matches_header():
-    # 8 pointers + 19 int32 (+4 pad) + 1 pointer
-    assert ctypes.sizeof(L.IgemmDesc) == 152
-    assert [f[0] for f in L.IgemmDesc._fields_][:8] == ["x", "x2", "w", "out", "partial", "bias", "rowvec", "residual"]
+def test_igemm_desc_layout_matches_header(tmp_path):
+    """The ctypes mirror of ``dadd_igemm_desc`` against the C compiler's view of include/dadd_hip.h (size and the
+    offset of every field)."""
+    import subprocess
+    fields = [f[0] for f in L.IgemmDesc._fields_]
+    assert fields[:8] == ["x", "x2", "w", "out", "partial", "bias", "rowvec", "residual"]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dadd_hip.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(dadd_igemm_desc));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof(dadd_igemm_desc, {f}));\n' for f in fields)
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert ctypes.sizeof(L.IgemmDesc) == out[0]
+    assert [getattr(L.IgemmDesc, f).offset for f in fields] == out[1:]
 
 
 def test_status_codes_map_to_reference_exceptions():

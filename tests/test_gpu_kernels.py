@@ -392,6 +392,18 @@ def test_tri_xattn_lambda_zero_equals_two_pathways(hip):
     hip.tri_xattn(dev(hip, q), dev(hip, kv2), o2, g, 0.0, 0, heads)
     hip.synchronize()
     assert torch.equal(o1.cpu(), o2.cpu())
+    # lambda as a DEVICE-side parameter (one captured graph serves a lambda sweep): the three-pathway kernel is
+    # launched and skips the delta pathway itself when the value it reads is 0 — same bits, NaN tokens never read
+    lam = dev(hip, torch.tensor([0.0]))
+    o3, o4 = hip.zeros((b, n, c), F16), hip.zeros((b, n, c), F16)
+    hip.tri_xattn(dev(hip, q), dev(hip, kv2), o3, g, 123.0, 0, heads, lam_dev=lam)       # the by-value lambda is ignored
+    hip.copy_(lam, torch.tensor([1.5]))
+    hip.tri_xattn(dev(hip, q), dev(hip, kv), o4, g, 0.0, 0, heads, lam_dev=lam)
+    o5 = hip.zeros((b, n, c), F16)
+    hip.tri_xattn(dev(hip, q), dev(hip, kv), o5, g, 1.5, 0, heads)
+    hip.synchronize()
+    assert torch.equal(o3.cpu(), o1.cpu()) and torch.equal(o4.cpu(), o5.cpu())
+    assert not torch.equal(o4.cpu(), o1.cpu())
 
 
 def test_thin_convs_and_pack(hip):

@@ -525,3 +525,38 @@ def test_module_vae_encode_on_device(full_sd):
     assert torch.equal(mod.vae.encode(x).latent_dist.mode(), dist.mean)
     img = mod.vae.decode(dist.mode()).sample
     assert img.shape == (2, 3, 128, 128) and float(img.min()) >= -1.0 and float(img.max()) <= 1.0
+
+
+def test_one_graph_serves_a_lambda_sweep(full_sd):
+    """lambda (and the CFG scale) are device-side parameters of the captured step (the reference
+    reads ``delta_scale`` per call, attention_processor_routing_gates.py:160): after runs at three lambdas the loop
+    holds ONE graph, every replay equals the eager run of the same lambda bit for bit, lambda = 0 equals the
+    two-pathway result even with NaN planted in the delta tokens' projections."""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 256, 2)
+    target, source = torch.tensor([3.0, 0.5], device=DEV), torch.tensor([0.0, 2.0], device=DEV)
+    pix = (torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(77))
+    loop = mod.ddim_loop(2, 32)
+    outs = {}
+    with torch.no_grad():
+        for lam in (3.0, 0.0, 1.25, 3.0):
+            z = PIPE._ddim_sample_ip(mod, target, source, pix, 4, DEV, steer_scale=lam, latents=lat)
+            if lam in outs:
+                assert torch.equal(z, outs[lam])
+            outs[lam] = z
+            z_e = PIPE._ddim_sample_ip(mod, target, source, pix, 4, DEV, steer_scale=lam, latents=lat, use_graph=False)
+            assert torch.equal(z, z_e), lam
+    assert len(loop.graphs) == 1
+    assert (outs[3.0] - outs[0.0]).abs().max().item() > 1e-3 and (outs[1.25] - outs[0.0]).abs().max().item() > 1e-3
+    # NaN in the delta rows of every K/V cache: lambda = 0 must not read them
+    with torch.no_grad():
+        PIPE._ddim_sample_ip(mod, target, source, pix, 1, DEV, steer_scale=0.0, latents=lat)     # projects the cond
+        for site, _ in loop.u.sites:
+            loop.u.kv[site][0][:, :, 32:, :] = float("nan")
+        loop.u._a2_dirty = True
+        loop.prepare(torch.linspace(999, 0, 4, dtype=torch.long), mod.alphas_cumprod)
+        loop.be.copy_(loop.u.lat_in, lat.to(DEV))
+        loop.run(0.0)
+        z_nan = loop.be.clone(loop.u.lat_in)
+    assert torch.equal(z_nan, outs[0.0])

@@ -160,7 +160,9 @@ class TorchRefBackend:
             y = y + bias.float()
         out.copy_((y + residual.float()).to(out.dtype))
 
-    def tri_xattn(self, q, kv, out, gates, lam, mode, heads):
+    def tri_xattn(self, q, kv, out, gates, lam, mode, heads, lam_dev=None):
+        if lam_dev is not None:
+            lam = float(lam_dev.reshape(-1)[0])
         b, n, c = q.shape
         d = c // heads
         qh = q.float().view(b, n, heads, d).transpose(1, 2)
@@ -195,7 +197,9 @@ class TorchRefBackend:
         cur_coef.copy_(coef[r])
         step += 1
 
-    def ddim_update(self, x, eps_c, eps_u, guidance, coef):
+    def ddim_update(self, x, eps_c, eps_u, guidance, coef, guidance_dev=None):
+        if guidance_dev is not None:
+            guidance = float(guidance_dev.reshape(-1)[0])
         e = eps_c if eps_u is None else eps_u + guidance * (eps_c - eps_u)
         x0 = ((x - coef[1] * e) / coef[0]).clamp(-4.0, 4.0)
         x.copy_(x0 if coef[2] < 0 else coef[2] * x0 + coef[3] * e)
