@@ -190,7 +190,7 @@ def main():
 
     cfg = default_config(**{"dataset.image_size": a.image_size})
     gates = {"anatomy": (0.1, 0.9), "disease": (0.9, 0.1), "both": (0.5, 0.5)}
-    tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+    tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1,
                 image_size=224, patch_size=14, projection_dim=32) if a.tiny_clip else None
     shapes = dict(W.unet_shapes())
     shapes.update(W.vae_shapes(encoder=False))

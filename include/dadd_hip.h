@@ -38,6 +38,10 @@ extern "C" {
 #define DADD_EPI_LNFOLD 128 /* a LayerNorm over the K (= channel) axis of x folded into this linear: w carries gamma,
                               bias the composed (w beta + b), ln_c1[n] = sum_k w[n][k]; the kernel derives the row
                               mean / rstd from the A fragments it reads anyway: out = rstd (acc - mu c1) + bias */
+#define DADD_EPI_QUICKGELU 256 /* x * sigmoid(1.702 x) after bias (CLIP MLP, transformers quick_gelu) */
+#define DADD_EPI_GELU 512      /* exact-form GELU after bias (nn.GELU of the resampler / purifier MLPs) */
+#define DADD_EPI_SIGMOID 1024  /* sigmoid after bias (FeaturePurifier gate) */
+#define DADD_EPI_ACT_MASK (256 | 512 | 1024)
 #define DADD_TUNE_SHALLOW 16 /* tuning: keep one K tile in flight instead of two (A/B measurements) */
 #define DADD_TUNE_NODMA 32   /* tuning: register-staged kernel instead of the LDS-DMA ring kernel */
 #define DADD_TUNE_PERSIST 64 /* tuning: LDS-DMA ring kept running over several output tiles per workgroup */
@@ -130,6 +134,12 @@ int dadd_layernorm_f16(const void* x, const float* gamma, const float* beta, voi
  * (src/models/attention_processor_routing_gates.py:286) and the VAE mid-block attention. */
 int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int N,
                        int heads, int d, int ld_qkv, int ld_out, void* stream);
+/* The same kernel with separate query / key-value sequences (Nq x Nk) and strides: d in {40,64,80,96,160,512}.
+ * Replaces the SDPA inside transformers' CLIPAttention (src/models/image_encoder.py:34-88, 257 tokens, 16 x 64) and
+ * nn.MultiheadAttention(768, 8) of the Resampler (image_encoder.py:152-228, 16 latents x 257 tokens) and of the
+ * FeaturePurifier (src/models/feature_purifier.py:49-53,83-87, 16 x 16 tokens). */
+int dadd_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int Nq, int Nk, int heads,
+                  int d, int ld_q, int ld_kv, int ld_out, void* stream);
 
 /* Fused DADD cross-attention.  q: [B][N][C]; kv: [B][T][ld_kv] holds the step-invariant
  * projections of the conditioning tokens: columns [0,C)=to_k, [C,2C)=to_v, [2C,3C)=to_k_dis,
@@ -161,9 +171,10 @@ int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const 
  * Sinusoidal timestep features (flip_sin_to_cos, shift 0): out[m][0:dim/2]=cos, [dim/2:]=sin. */
 int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream);
 /* out[m][n] = act_out( sum_k act_in(x[m][k]) * w[n][k] + bias[n] ), fp32 rows, fp16 weights,
- * M small (time-embedding MLP, per-resblock time_emb_proj).  act: 0 none, 1 SiLU. */
+ * M small (time-embedding MLP, per-resblock time_emb_proj; with w_f32 = 1 fp32 weights: the AOE projector
+ * MLP, src/models/ordinal_embedder.py:107-127).  act: 0 none, 1 SiLU, 2 GELU (exact). */
 int dadd_linear_rows_f32(const float* x, const void* w, const float* bias, float* out, int M, int K,
-                         int N, int act_in, int act_out, void* stream);
+                         int N, int act_in, int act_out, int w_f32, void* stream);
 /* Per-step prologue run from inside the captured graph: row = *step;
  * cur_rows[b][:] = table[row][:] for b < B; cur_coef[0:4] = coef[row][0:4]; then *step += 1. */
 int dadd_begin_step(const float* table, float* cur_rows, int B, int ncols, const float* coef,
@@ -174,6 +185,20 @@ int dadd_begin_step(const float* table, float* cur_rows, int B, int ncols, const
  * sqrt(1-ab_prev)} and last encoded as c2 < 0.  `guidance_dev` (device float, optional) overrides `guidance`. */
 int dadd_ddim_update_f32(float* x, const float* eps_c, const float* eps_u, float guidance,
                          const float* guidance_dev, const float* coef, int64_t n, void* stream);
+
+/* ---- conditioning front-end (once per batch): the pieces around the GEMM / attention kernels ---------------
+ * CLIP patch rows: pixel_values [B][3][H][W] fp32 -> [B][1 + (H/P)(W/P)][Kp] fp16, row 0 of a sample zero (class
+ * token slot), patch elements in conv-weight order (c, ky, kx), zero padded to Kp (multiple of 64): the operand of
+ * the patch-embedding GEMM (CLIPVisionEmbeddings.patch_embedding, src/models/image_encoder.py:34-42). */
+int dadd_clip_patch_rows_f16(const float* pixels, void* out, int B, int H, int W, int patch, int Kp, void* stream);
+/* AOE class interpolation (src/models/ordinal_embedder.py:129-182): out[b][:] = lerp over table = base + cumsum(deltas)
+ * at label[b] clamped to [0, classes-1]; fp32. */
+int dadd_aoe_interp_f32(const float* labels, const float* base, const float* deltas, float* out, int B, int D,
+                        int classes, void* stream);
+/* FeaturePurifier tail (src/models/feature_purifier.py:88-95): out = LayerNorm(img - gate * dis); fp16 rows in,
+ * fp32 rows out; gate already passed through the sigmoid. */
+int dadd_purifier_tail_f16(const void* img, const void* dis, const void* gate, const float* gamma,
+                           const float* beta, float* out, int M, int C, float eps, void* stream);
 
 /* ---- hipGraph capture of the step loop ----------------------------------------------------- */
 int dadd_graph_begin(void* stream);

@@ -170,11 +170,36 @@ class HipBackend:
         L.check(self.lib.dadd_timestep_features_f32(_p(t), _p(out), out.shape[0], out.shape[1], self.s))
 
     def linear_rows(self, x, w, bias, out, act_in=0, act_out=0):
+        """fp32 rows x (fp16 or fp32) weights; act 0 none, 1 SiLU, 2 GELU."""
         m, k = x.shape
         n = w.shape[0]
         assert w.shape[1] == k and out.shape == (m, n) and x.dtype == torch.float32
+        assert w.dtype in (torch.float16, torch.float32)
         L.check(self.lib.dadd_linear_rows_f32(_p(x), _p(w), _p(bias), _p(out), m, k, n, act_in,
-                                              act_out, self.s))
+                                              act_out, int(w.dtype == torch.float32), self.s))
+
+    def attention(self, q, k, v, out, heads):
+        """softmax(q k^T / sqrt(d)) v with separate query / key-value lengths: q [B,Nq,*], k, v [B,Nk,*] (views
+        into wider rows are fine: the row strides travel), out [B,Nq,C]."""
+        b, nq, c = out.shape
+        nk = k.shape[1]
+        assert q.shape[:2] == (b, nq) and v.shape[:2] == (b, nk) and k.stride(1) == v.stride(1)
+        L.check(self.lib.dadd_attn_f16(_p(q), _p(k), _p(v), _p(out), b, nq, nk, heads, c // heads, q.stride(1),
+                                       k.stride(1), out.stride(1), self.s))
+
+    def clip_patch_rows(self, pixels, out, patch):
+        b, _, h, w = pixels.shape
+        assert pixels.dtype == torch.float32 and out.dtype == torch.float16 and out.shape[0] == b
+        L.check(self.lib.dadd_clip_patch_rows_f16(_p(pixels), _p(out), b, h, w, patch, out.shape[-1], self.s))
+
+    def aoe_interp(self, labels, base, deltas, out):
+        L.check(self.lib.dadd_aoe_interp_f32(_p(labels), _p(base), _p(deltas), _p(out), labels.shape[0],
+                                             out.shape[1], deltas.shape[0] + 1, self.s))
+
+    def purifier_tail(self, img, dis, gate, gamma, beta, out, eps=1e-5):
+        c = img.shape[-1]
+        L.check(self.lib.dadd_purifier_tail_f16(_p(img), _p(dis), _p(gate), _p(gamma), _p(beta), _p(out),
+                                                img.numel() // c, c, float(eps), self.s))
 
     def begin_step(self, table, cur_rows, coef, cur_coef, step):
         L.check(self.lib.dadd_begin_step(_p(table), _p(cur_rows), cur_rows.shape[0], table.shape[1],

@@ -50,7 +50,7 @@ struct FlashArgs {
   const half_t* k;
   const half_t* v;
   half_t* out;
-  int B, N, H, ld, ldo;
+  int B, Nq, N, H, ldq, ld, ldo;   // Nq query rows (ldq), N key / value rows (ld) per sample
   float scale_log2;  // log2(e)/sqrt(d)
 };
 
@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) run on ONE XCD, so its K/V (0.6-1.3 MB)
   // is fetched into one L2 instead of all eight (FETCH_SIZE 170 MB -> ~1/5 for 4x4096x8x40)
-  const int nqb = (p.N + 64 * QF - 1) / (64 * QF);
+  const int nqb = (p.Nq + 64 * QF - 1) / (64 * QF);
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = tile / nqb, qb = tile - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
   const int qw0 = qb * (64 * QF) + wave * (16 * QF);
-  const size_t tok0 = (size_t)b * p.N;
+  const size_t tok0 = (size_t)b * p.N, qtok0 = (size_t)b * p.Nq;
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // zero both buffers once (padding columns are never written again); ones column for the row sums
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
     int qrow = qw0 + f * 16 + li;
-    if (qrow > p.N - 1) qrow = p.N - 1;
-    const half_t* qp = p.q + (tok0 + qrow) * p.ld + h * DR;
+    if (qrow > p.Nq - 1) qrow = p.Nq - 1;
+    const half_t* qp = p.q + (qtok0 + qrow) * p.ldq + h * DR;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int dc = 32 * s + 8 * g;
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
       l = __shfl(oacc[DR / 16][f][DR % 4], ((DR % 16) / 4) * 16 + li, 64);
     }
     const int qrow = qw0 + f * 16 + li;
-    if (qrow >= p.N) continue;
+    if (qrow >= p.Nq) continue;
     const float inv = 1.0f / l;
-    half_t* op = p.out + (tok0 + qrow) * p.ldo + h * DR;
+    half_t* op = p.out + (qtok0 + qrow) * p.ldo + h * DR;
 #pragma unroll
     for (int df = 0; df < DF; ++df) {
       const int dcol = df * 16 + 4 * g;
@@ -517,10 +517,10 @@ template <int DR, int QF, bool PF>
 int launch_flash(const FlashArgs& a, hipStream_t s) {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int smem = (PF ? 2 : 1) * (((D + 63) / 64) * 4096 + 64 * v_stride(DVP)) * (int)sizeof(half_t);
-  dim3 grid(((a.N + 64 * QF - 1) / (64 * QF)) * a.B * a.H);
+  dim3 grid(((a.Nq + 64 * QF - 1) / (64 * QF)) * a.B * a.H);
   static const std::string name = "flash_kernel<" + std::to_string(DR) + ", " + std::to_string(QF) + ", " + (PF ? "true" : "false") + ">";
-  const double tok = (double)a.B * a.N, c = (double)a.H * DR;
-  dadd_launch({name.c_str(), 4.0 * tok * a.N * c, tok * c * 2.0 * 4.0}, flash_kernel<DR, QF, PF>, grid, dim3(256), smem, s, a);
+  const double tok = (double)a.B * a.Nq, c = (double)a.H * DR;
+  dadd_launch({name.c_str(), 4.0 * tok * a.N * c, (tok + (double)a.B * a.N) * c * 2.0 * 2.0}, flash_kernel<DR, QF, PF>, grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
@@ -547,39 +547,48 @@ int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
 int dadd_init_attention() {
   int rc = flash_attr<40, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<40, 4, true>();
+  if (rc == DADD_OK) rc = flash_attr<64, 2, true>();
+  if (rc == DADD_OK) rc = flash_attr<96, 1, true>();
   if (rc == DADD_OK) rc = flash_attr<80, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<160, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<512, 1, false>();
   return rc;
 }
 
-extern "C" int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B,
-                                  int N, int heads, int d, int ld_qkv, int ld_out, void* stream) {
-  DADD_REQUIRE(q && k && v && out, "self_attn: null pointer");
-  DADD_REQUIRE(B > 0 && N > 0 && heads > 0, "self_attn: empty problem");
-  DADD_REQUIRE(ld_qkv % 8 == 0 && ld_out % 4 == 0 && ld_qkv >= heads * d && ld_out >= heads * d,
-               "self_attn: bad leading dimensions");
+extern "C" int dadd_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int Nq, int Nk,
+                             int heads, int d, int ld_q, int ld_kv, int ld_out, void* stream) {
+  DADD_REQUIRE(q && k && v && out, "attn: null pointer");
+  DADD_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && heads > 0, "attn: empty problem");
+  DADD_REQUIRE(ld_q % 8 == 0 && ld_kv % 8 == 0 && ld_out % 4 == 0 && ld_q >= heads * d && ld_kv >= heads * d &&
+                   ld_out >= heads * d, "attn: bad leading dimensions");
   DADD_REQUIRE(dadd_aligned16(q) && dadd_aligned16(k) && dadd_aligned16(v) && dadd_aligned16(out),
-               "self_attn: pointers must be 16-byte aligned");
+               "attn: pointers must be 16-byte aligned");
   FlashArgs a;
   a.q = static_cast<const half_t*>(q);
   a.k = static_cast<const half_t*>(k);
   a.v = static_cast<const half_t*>(v);
   a.out = static_cast<half_t*>(out);
-  a.B = B; a.N = N; a.H = heads; a.ld = ld_qkv; a.ldo = ld_out;
+  a.B = B; a.Nq = Nq; a.N = Nk; a.H = heads; a.ldq = ld_q; a.ld = ld_kv; a.ldo = ld_out;
   a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d) {
     case 40:   // 64 queries per wave once the grid still fills the chip (>= 2 blocks per CU)
-      return ((long)B * heads * ((N + 255) / 256) >= 512)
+      return ((long)B * heads * ((Nq + 255) / 256) >= 512)
                  ? launch_flash<40, 4, true>(a, s) : launch_flash<40, 2, true>(a, s);
+    case 64: return launch_flash<64, 2, true>(a, s);     // CLIP ViT towers (257 tokens, 16 x 64)
     case 80: return launch_flash<80, 2, true>(a, s);
+    case 96: return launch_flash<96, 1, true>(a, s);     // nn.MultiheadAttention(768, 8) of the resampler / purifier
     case 160: return launch_flash<160, 2, true>(a, s);
     case 512: return launch_flash<512, 1, false>(a, s);
     default:
-      dadd_set_error("self_attn: unsupported head dim %d (40, 80, 160, 512)", d);
+      dadd_set_error("attn: unsupported head dim %d (40, 64, 80, 96, 160, 512)", d);
       return DADD_EINVAL;
   }
+}
+
+extern "C" int dadd_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B,
+                                  int N, int heads, int d, int ld_qkv, int ld_out, void* stream) {
+  return dadd_attn_f16(q, k, v, out, B, N, N, heads, d, ld_qkv, ld_qkv, ld_out, stream);
 }
 
 extern "C" int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* gates,

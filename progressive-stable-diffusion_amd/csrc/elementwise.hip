@@ -135,10 +135,26 @@ __global__ void timestep_features_kernel(const int64_t* __restrict__ t, float* _
   out[(size_t)m * dim + half + j] = sinf(ang);
 }
 
+__device__ __forceinline__ float rows_act(float v, int act) {   // 0 none, 1 SiLU, 2 exact GELU (libm erf: fp32 path)
+  return act == 1 ? dadd_silu(v) : (act == 2 ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)) : v);
+}
+__device__ __forceinline__ void rows_load8(const half_t* p, float (&o)[8]) {
+  const h8 v = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = (float)v[c];
+}
+__device__ __forceinline__ void rows_load8(const float* p, float (&o)[8]) {
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { o[c] = a[c]; o[c + 4] = b[c]; }
+}
+
 // out[m][n] = act_out(sum_k act_in(x[m][k]) w[n][k] + bias[n]); one wave per output column,
-// up to 8 rows of x staged in LDS per pass.
+// up to 8 rows of x staged in LDS per pass.  WT = half_t (time-embedding path) or float (AOE projector: its delta
+// tokens are differences of two outputs, kept at fp32 weight fidelity).
+template <typename WT>
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x,
-                                                          const half_t* __restrict__ w,
+                                                          const WT* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ out, int M, int K, int N,
                                                           int act_in, int act_out) {
@@ -150,8 +166,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
     const int mr = min(8, M - m0);
     __syncthreads();
     for (int i = threadIdx.x; i < mr * K; i += 256) {
-      float v = x[(size_t)m0 * K + i];
-      xs[i] = act_in ? dadd_silu(v) : v;
+      xs[i] = rows_act(x[(size_t)m0 * K + i], act_in);
     }
     __syncthreads();
     if (n >= N) continue;
@@ -159,13 +174,14 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = 0.f;
     for (int ch = lane; ch < nchunk; ch += 64) {
-      const h8 wv = *reinterpret_cast<const h8*>(w + (size_t)n * K + ch * 8);
+      float wv[8];
+      rows_load8(w + (size_t)n * K + ch * 8, wv);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         if (r < mr) {
           const float* xr = xs + r * K + ch * 8;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[r] += xr[c] * (float)wv[c];
+          for (int c = 0; c < 8; ++c) acc[r] += xr[c] * wv[c];
         }
       }
     }
@@ -173,8 +189,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
     for (int r = 0; r < 8; ++r) {
       const float s = wave_sum(acc[r]);
       if (lane == 0 && r < mr) {
-        float v = s + (bias ? bias[n] : 0.f);
-        out[(size_t)(m0 + r) * N + n] = act_out ? dadd_silu(v) : v;
+        out[(size_t)(m0 + r) * N + n] = rows_act(s + (bias ? bias[n] : 0.f), act_out);
       }
     }
   }
@@ -300,13 +315,19 @@ extern "C" int dadd_timestep_features_f32(const int64_t* t, float* out, int M, i
 }
 
 extern "C" int dadd_linear_rows_f32(const float* x, const void* w, const float* bias, float* out, int M,
-                                    int K, int N, int act_in, int act_out, void* stream) {
+                                    int K, int N, int act_in, int act_out, int w_f32, void* stream) {
   DADD_REQUIRE(x && w && out, "linear_rows: null pointer");
   DADD_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && K <= 2048, "linear_rows: K must be x8, <=2048");
   DADD_REQUIRE(dadd_aligned16(w), "linear_rows: w must be 16-byte aligned");
-  dadd_launch({"linear_rows_kernel", 2.0 * M * N * K, 2.0 * N * K + 4.0 * M * (K + N)}, linear_rows_kernel, dim3((N + 3) / 4), dim3(256), (unsigned)(8 * K * sizeof(float)),
-                     static_cast<hipStream_t>(stream), x, static_cast<const half_t*>(w), bias, out, M,
-                     K, N, act_in, act_out);
+  DADD_REQUIRE(act_in >= 0 && act_in <= 2 && act_out >= 0 && act_out <= 2, "linear_rows: act must be 0, 1 (SiLU) or 2 (GELU)");
+  const DaddLaunchTag tag = {w_f32 ? "linear_rows_kernel<float>" : "linear_rows_kernel<_Float16>", 2.0 * M * N * K,
+                             (w_f32 ? 4.0 : 2.0) * N * K + 4.0 * M * (K + N)};
+  if (w_f32)
+    dadd_launch(tag, linear_rows_kernel<float>, dim3((N + 3) / 4), dim3(256), (unsigned)(8 * K * sizeof(float)),
+                static_cast<hipStream_t>(stream), x, static_cast<const float*>(w), bias, out, M, K, N, act_in, act_out);
+  else
+    dadd_launch(tag, linear_rows_kernel<half_t>, dim3((N + 3) / 4), dim3(256), (unsigned)(8 * K * sizeof(float)),
+                static_cast<hipStream_t>(stream), x, static_cast<const half_t*>(w), bias, out, M, K, N, act_in, act_out);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

@@ -250,7 +250,7 @@ int set_attr1() {
 template <int BM, int BN, bool DEEP>
 int set_attr() {
   const int rc = set_attr1<BM, BN, DEEP, false>();
-  return rc == DADD_OK ? set_attr1<BM, BN, DEEP, true>() : rc;
+  return (rc == DADD_OK && !DEEP) ? set_attr1<BM, BN, false, true>() : rc;
 }
 
 template <int BM, int BN, bool DEEP, bool LNF>
@@ -266,7 +266,8 @@ int launch1(const IgemmArgs& a, int nsplit, hipStream_t s) {
 }
 template <int BM, int BN, bool DEEP>
 int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
-  return (a.flags & DADD_EPI_LNFOLD) ? launch1<BM, BN, DEEP, true>(a, nsplit, s) : launch1<BM, BN, DEEP, false>(a, nsplit, s);
+  // (with the row statistics of a folded LayerNorm the two-tiles-in-flight variant spills: one tile in flight)
+  return (a.flags & DADD_EPI_LNFOLD) ? launch1<BM, BN, false, true>(a, nsplit, s) : launch1<BM, BN, DEEP, false>(a, nsplit, s);
 }
 
 template <int BM, int BN>
@@ -305,7 +306,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD);   // epilogue bits + the persistent-ring request
+  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK);   // epilogue bits + the persistent-ring request
   a.ln_c1 = d->ln_c1;
   a.ln_eps = d->ln_eps;
   const int Cin = a.C1 + a.C2;
@@ -330,6 +331,8 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   DADD_REQUIRE(!(a.flags & DADD_EPI_BIAS) || a.bias, "igemm: bias flag without bias");
   DADD_REQUIRE(!(a.flags & DADD_EPI_ROWVEC) || a.rowvec, "igemm: rowvec flag without rowvec");
   DADD_REQUIRE(!(a.flags & DADD_EPI_RESIDUAL) || a.residual, "igemm: residual flag without ptr");
+  DADD_REQUIRE(!(a.flags & DADD_EPI_ACT_MASK) || (!geglu && d->splitk <= 1),
+               "igemm: an activation epilogue excludes GEGLU and split-K");
   DADD_REQUIRE(!(a.flags & DADD_EPI_LNFOLD) || (a.ln_c1 && a.taps == 1 && a.C2 == 0 && d->splitk <= 1 && a.ln_eps > 0.f),
                "igemm: a folded LayerNorm needs c1, a plain linear over one source (K = C) and no split-K");
   DADD_REQUIRE(a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ld_rowvec % 4 == 0,

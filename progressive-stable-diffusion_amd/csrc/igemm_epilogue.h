@@ -102,6 +102,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
       if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const f4*>(p.bias + n);
       if (p.flags & DADD_EPI_ROWVEC)
         v += *reinterpret_cast<const f4*>(p.rowvec + (size_t)b * p.ld_rowvec + n);
+      if (p.flags & DADD_EPI_ACT_MASK) {      // activation of the linear itself, before any residual
+        if (p.flags & DADD_EPI_QUICKGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+        } else if (p.flags & DADD_EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = dadd_gelu(v[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + __expf(-v[r]));
+        }
+      }
       if (p.flags & DADD_EPI_RESIDUAL) {
         const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll

@@ -337,20 +337,21 @@ class DiffusionModuleWithIP:
         self.snr_values = (ac / (1.0 - ac + 1e-8)).to(self.device)
 
         self.ordinal_embedder = AdditiveOrdinalEmbedder(
-            state_dict, self.device, emb.num_classes, cfg.model.embedding_dim, dc.num_aoe_tokens)
+            state_dict, self.device, emb.num_classes, cfg.model.embedding_dim, dc.num_aoe_tokens, be=self.be)
         # The reference keeps the CLIP tower as an nn.Module child, so a Lightning state_dict carries
-        # ``image_encoder.image_encoder.*``.  Use those tensors when present; a caller-supplied
-        # state dict WITHOUT them gets a seeded random tower and a loud warning (bench / tests only).
-        clip_sd = {k[len(clip_pref):]: v for k, v in state_dict.items() if k.startswith(clip_pref)}
-        if not clip_sd and user_sd:
-            import warnings
-            warnings.warn("state dict has no 'image_encoder.image_encoder.*' tensors: the CLIP tower is SEEDED RANDOM "
-                          "(anatomy tokens are noise for a real checkpoint)", RuntimeWarning, stacklevel=2)
-        self.image_encoder = ImageEncoder(self.device, seed=seed, clip_config=clip_config,
-                                          state_dict=clip_sd or None)
+        # ``image_encoder.image_encoder.*``: those tensors are the tower.  A caller-supplied state
+        # dict WITHOUT them gets a seeded random tower and a loud warning (bench / tests only).
+        if (clip_pref + "visual_projection.weight") not in state_dict:
+            if user_sd:
+                import warnings
+                warnings.warn("state dict has no 'image_encoder.image_encoder.*' tensors: the CLIP tower is SEEDED RANDOM "
+                              "(anatomy tokens are noise for a real checkpoint)", RuntimeWarning, stacklevel=2)
+            state_dict = dict(state_dict)
+            state_dict.update(W.init_state_dict(W.clip_shapes(clip_config), seed))
+        self.image_encoder = ImageEncoder(state_dict, self.device, clip_config=clip_config, be=self.be)
         proj_cls = ImageProjectionPlus if dc.use_image_projection_plus else ImageProjection
-        self.image_projection = proj_cls(state_dict, self.device, dc.num_image_tokens)
-        self.feature_purifier = (FeaturePurifier(state_dict, self.device, dc.purifier_num_heads)
+        self.image_projection = proj_cls(state_dict, self.device, dc.num_image_tokens, be=self.be)
+        self.feature_purifier = (FeaturePurifier(state_dict, self.device, dc.purifier_num_heads, be=self.be)
                                  if dc.use_feature_purifier else None)
         self._unets: Dict[Tuple[int, int], OrdinalUNet] = {}
         self._loops: Dict[Tuple[int, int], DdimLoop] = {}

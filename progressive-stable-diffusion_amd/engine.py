@@ -88,8 +88,18 @@ def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
 
 
 # LayerNorm folded into the consuming linear (qkv, attn2.to_q, GEGLU projection) instead of a LayerNorm launch and a
-# normalised copy of the hidden states per transformer block.  Module-level switch for A/B measurements and tests.
-LN_FOLD = True
+# normalised copy of the hidden states.  Measured in situ (profiles/r02_d_step_profile_lnfold_everywhere.txt): the row
+# statistics are 64 v_dot2c per K tile in the MFMA waves — free where those waves wait on the LDS fill (64-row tiles:
+# 15.7 vs 15.3 us, minus a 4.7 us LayerNorm launch), but +11..19 us on the 128-row tiles, whose MFMA waves are the
+# critical path (qkv 64x64: 45 vs 26 us).  So "auto" folds exactly the linears planned on 64-row tiles; True / False
+# force it everywhere / nowhere (tests, A/B measurements).
+LN_FOLD = "auto"
+
+
+def fold_here(m: int, n: int, k: int, geglu: bool = False) -> bool:
+    if LN_FOLD == "auto":
+        return plan_tiling(m, n, k, 1, geglu, False)[0] == 64
+    return bool(LN_FOLD)
 
 
 def choose_tiling(m: int, n: int, k: int, tile_n: int, geglu: bool = False,
@@ -397,15 +407,17 @@ class UNetPlan(_Plan):
         b, h, w_, c = x.shape
         shp = (b, h, w_, c)
         tb = site + ".transformer_blocks.0"
-        fold = LN_FOLD
+        m_rows = b * h * w_
+        fold1, fold2, fold3 = (fold_here(m_rows, 3 * c, c), fold_here(m_rows, c, c) and site not in self.a2,
+                               fold_here(m_rows, 8 * c, c, True))
         g = self.gn(x, None, self.f(site + ".norm.weight"), self.f(site + ".norm.bias"), 1e-6, 0)
         hs = self.conv(g, self.w(site + ".proj_in.weight"), shp, bias=self.f(site + ".proj_in.bias"),
                        taps=1, pad=0)
         self.pool.put(g)
-        need_ln = (not fold) or site in self.a2        # the fused attn2 kernel reads a normalised copy
+        need_ln = not (fold1 and fold2 and fold3)      # (the fused attn2 kernel reads a normalised copy)
         ln = self.pool.get(shp) if need_ln else None
         # attn1 (self)
-        if fold:
+        if fold1:
             wqkv, c1, bqkv = self._ln_linear(tb, ".norm1", "qkv", [f".attn1.to_{n}.weight" for n in "qkv"])
             qkv = self.conv(hs, wqkv, (b, h, w_, 3 * c), bias=bqkv, taps=1, pad=0, ln_c1=c1)
         else:
@@ -427,7 +439,7 @@ class UNetPlan(_Plan):
             self.rec(self.be.attn2_fused, ln.view(b, h * w_, c), st["mcat"], st["vw"],
                      self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c))
         else:
-            if fold:
+            if fold2:
                 wq, c1, bq = self._ln_linear(tb, ".norm2", "to_q", [".attn2.to_q.weight"])
                 q = self.conv(h2, wq, shp, bias=bq, taps=1, pad=0, ln_c1=c1)
             else:
@@ -439,7 +451,7 @@ class UNetPlan(_Plan):
                            bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0)
         self.pool.put(h2, att)
         # GEGLU feed-forward
-        if fold:
+        if fold3:
             wf, c1, bf = self._ln_linear(tb, ".norm3", "geglu", [".ff.net.0.proj.weight"], ".ff.net.0.proj.bias", geglu=True)
             ff = self.conv(h3, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU, ln_c1=c1)
         else:

@@ -12,11 +12,12 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdadd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "attn2_fused.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.hip")
+SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "attn2_fused.hip", "norm.hip", "attention.hip", "elementwise.hip",
+           "conditioning.hip", "api.hip")
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
-EPI_LNFOLD = 128
+EPI_LNFOLD, EPI_QUICKGELU, EPI_GELU, EPI_SIGMOID = 128, 256, 512, 1024
 TUNE_SHALLOW, TUNE_NODMA, TUNE_PERSIST = 16, 32, 64
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
 GN_MAX_CHUNKS = 256
@@ -54,7 +55,11 @@ PROTOTYPES = {
     "dadd_tri_xattn_f16": (C.c_int, [vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
     "dadd_timestep_features_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
-    "dadd_linear_rows_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_linear_rows_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_attn_f16": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 8 + [vp]),
+    "dadd_clip_patch_rows_f16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_aoe_interp_f32": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_purifier_tail_f16": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
     "dadd_begin_step": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "dadd_ddim_update_f32": (C.c_int, [vp, vp, vp, f32, vp, vp, i64, vp]),
     "dadd_graph_begin": (C.c_int, [vp]),

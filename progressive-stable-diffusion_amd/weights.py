@@ -202,6 +202,34 @@ def conditioning_shapes(num_classes=4, dim=COND_DIM, num_tokens=16, clip_hidden=
     return d
 
 
+CLIP_VIT_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+                    image_size=224, patch_size=14, projection_dim=768)
+
+
+def clip_shapes(cfg: Optional[dict] = None, prefix="image_encoder.image_encoder") -> "OrderedDict[str, Shape]":
+    """transformers ``CLIPVisionModelWithProjection`` parameters (its key names) under the reference's module path
+    (``ImageEncoder.image_encoder``, src/models/image_encoder.py:34-42)."""
+    c = dict(cfg or CLIP_VIT_L14)
+    h, inter, p = c["hidden_size"], c["intermediate_size"], c["patch_size"]
+    d: "OrderedDict[str, Shape]" = OrderedDict()
+    v = prefix + ".vision_model."
+    d[v + "embeddings.class_embedding"] = (h,)
+    d[v + "embeddings.patch_embedding.weight"] = (h, 3, p, p)
+    d[v + "embeddings.position_embedding.weight"] = ((c["image_size"] // p) ** 2 + 1, h)
+    _norm(d, v + "pre_layrnorm", h)
+    for i in range(c["num_hidden_layers"]):
+        lp = v + f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            _lin(d, lp + "self_attn." + n, h, h)
+        _norm(d, lp + "layer_norm1", h)
+        _lin(d, lp + "mlp.fc1", inter, h)
+        _lin(d, lp + "mlp.fc2", h, inter)
+        _norm(d, lp + "layer_norm2", h)
+    _norm(d, v + "post_layernorm", h)
+    d[prefix + ".visual_projection.weight"] = (c["projection_dim"], h)
+    return d
+
+
 # ----------------------------------------------------------------------------- init
 def _gen(key: str, seed: int) -> torch.Generator:
     g = torch.Generator(device="cpu")
@@ -211,7 +239,7 @@ def _gen(key: str, seed: int) -> torch.Generator:
 
 def _is_norm_key(key: str) -> bool:
     leaf = key.rsplit(".", 2)[-2] if key.count(".") >= 1 else ""
-    return (leaf.startswith("norm") or leaf in ("group_norm", "conv_norm_out")
+    return (leaf.startswith(("norm", "layer_norm")) or leaf in ("group_norm", "conv_norm_out", "pre_layrnorm", "post_layernorm")
             or leaf in ("norm_img", "norm_aoe", "norm_out"))
 
 
@@ -235,6 +263,8 @@ def init_tensor(key: str, shape: Shape, seed: int, gates: Optional[Dict[str, Tup
     if key == "ordinal_embedder.null_embedding":
         return torch.zeros(shape)
     if key == "image_projection.latents":
+        return torch.randn(shape, generator=g) * 0.02
+    if key.endswith(("class_embedding", "position_embedding.weight")):
         return torch.randn(shape, generator=g) * 0.02
     if _is_norm_key(key):
         n = torch.randn(shape, generator=g) * 0.1

@@ -150,9 +150,10 @@ def test_igemm_layernorm_fold(hip, tile_m, tile_n, tune, geglu):
               ln_c1=dev(hip, c1.contiguous()))
     hip.synchronize()
     close(o, ref, 6e-3, 6e-3, f"ln fold {tile_m}x{tile_n} tune{tune} geglu{geglu}")
-    with pytest.raises(ValueError):       # a folded LayerNorm needs whole rows of A: no split-K
-        hip.igemm(dev(hip, x), dev(hip, w16.contiguous()), o, flags=L.EPI_LNFOLD, splitk=2, partial=hip.zeros((2 * m * n,), F32),
-                  ln_c1=dev(hip, c1.contiguous()))
+    if not geglu:
+        with pytest.raises(ValueError):       # a folded LayerNorm needs whole rows of A: no split-K
+            hip.igemm(dev(hip, x), dev(hip, w16.contiguous()), o, flags=L.EPI_LNFOLD, splitk=2,
+                      partial=hip.zeros((2 * m * n,), F32), ln_c1=dev(hip, c1.contiguous()))
 
 
 @pytest.mark.parametrize("taps", [1, 9])
@@ -524,3 +525,71 @@ def test_profiling_hooks(hip):
             assert flop == 0.0 and byt == pytest.approx(256 * 320 * 4.0)
     hip.igemm(xd, wd, o)          # not recorded any more
     assert hip.prof_end.__self__ is hip
+
+
+# ------------------------------------------------------------------------------------------------ conditioning front-end
+@pytest.mark.parametrize("d,heads,nq,nk", [(64, 16, 257, 257), (64, 1, 257, 257), (96, 8, 16, 257), (96, 8, 16, 16), (40, 8, 100, 300)])
+def test_attention_separate_query_and_key_lengths(hip, d, heads, nq, nk):
+    """dadd_attn_f16: q rows and k/v rows of different counts, read as strided views of wider rows (the fused q|k|v
+    and k|v projections of CLIP / nn.MultiheadAttention); d = 64 (CLIP) and 96 (768 / 8 heads)."""
+    b, c = 2, heads * d
+    qkv_q = rnd((b, nq, 3 * c), 40)
+    kv = rnd((b, nk, 2 * c), 41)
+    o_ref = torch.zeros(b, nq, c, dtype=F16)
+    REF.attention(qkv_q[:, :, :c], kv[:, :, :c], kv[:, :, c:], o_ref, heads)
+    qd, kvd = dev(hip, qkv_q), dev(hip, kv)
+    o = hip.zeros((b, nq, c), F16)
+    hip.attention(qd[:, :, :c], kvd[:, :, :c], kvd[:, :, c:], o, heads)
+    hip.synchronize()
+    close(o, o_ref, 3e-3, 3e-3, f"attention d{d} {nq}x{nk}")
+
+
+@pytest.mark.parametrize("act,flag", [("quick_gelu", 256), ("gelu", 512), ("sigmoid", 1024)])
+def test_igemm_activation_epilogues(hip, act, flag):
+    import torch.nn.functional as Fn
+    m, n, k = 300, 512, 256
+    x, w = rnd((1, m, 1, k), 42), rnd((n, k), 43, 1 / math.sqrt(k) * 3)
+    bias, res = rnd((n,), 44, 0.3, F32), rnd((1, m, 1, n), 45)
+    y = Fn.linear(x.float(), w.float(), bias)
+    y = {"quick_gelu": y * torch.sigmoid(1.702 * y), "gelu": Fn.gelu(y), "sigmoid": torch.sigmoid(y)}[act] + res.float()
+    o = hip.zeros((1, m, 1, n), F16)
+    hip.igemm(dev(hip, x), dev(hip, w), o, bias=dev(hip, bias), residual=dev(hip, res), flags=1 | 4 | flag)
+    hip.synchronize()
+    close(o, y, 3e-3, 3e-3, act)
+    with pytest.raises(ValueError):      # no activation on split-K slabs
+        hip.igemm(dev(hip, x), dev(hip, w), o, flags=flag, splitk=2, partial=hip.zeros((2 * m * n,), F32))
+
+
+def test_conditioning_small_kernels(hip):
+    import torch.nn.functional as Fn
+    g = torch.Generator().manual_seed(46)
+    # CLIP patch rows
+    px = torch.randn(2, 3, 28, 42, generator=g)
+    rows = hip.zeros((2, 1 + 2 * 3, 640), F16)
+    hip.clip_patch_rows(dev(hip, px), rows, 14)
+    ref = torch.zeros(2, 7, 640, dtype=F16)
+    REF.clip_patch_rows(px, ref, 14)
+    hip.synchronize()
+    assert torch.equal(rows.cpu(), ref) and float(rows[:, 0].abs().max()) == 0.0
+    # AOE interpolation (labels outside [0, 3] clamp, fractional labels lerp) — fp32, bit-for-bit the torch ops
+    labels = torch.tensor([0.0, 0.25, 1.0, 1.6, 3.0, 3.7, -0.5])
+    base, deltas = torch.randn(768, generator=g) * 0.02, torch.randn(3, 768, generator=g) * 0.05
+    out, oref = hip.zeros((7, 768), F32), torch.zeros(7, 768)
+    hip.aoe_interp(dev(hip, labels), dev(hip, base), dev(hip, deltas), out)
+    REF.aoe_interp(labels, base, deltas, oref)
+    hip.synchronize()
+    assert (out.cpu() - oref).abs().max().item() < 1e-6
+    # fp32-weight rows kernel with GELU (AOE projector)
+    x, w, b = torch.randn(5, 768, generator=g), torch.randn(1536, 768, generator=g) / 28, torch.randn(1536, generator=g) * 0.1
+    o = hip.zeros((5, 1536), F32)
+    hip.linear_rows(dev(hip, x), dev(hip, w), dev(hip, b), o, 0, 2)
+    hip.synchronize()
+    assert (o.cpu() - Fn.gelu(Fn.linear(x, w, b))).abs().max().item() < 2e-5
+    # purifier tail
+    img, dis, gate = rnd((2, 16, 768), 47), rnd((2, 16, 768), 48), torch.rand(2, 16, 768, generator=g).to(F16)
+    gam, bet = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    o, oref = hip.zeros((2, 16, 768), F32), torch.zeros(2, 16, 768)
+    hip.purifier_tail(dev(hip, img), dev(hip, dis), dev(hip, gate), dev(hip, gam), dev(hip, bet), o)
+    REF.purifier_tail(img, dis, gate, gam, bet, oref)
+    hip.synchronize()
+    assert (o.cpu() - oref).abs().max().item() < 2e-5

@@ -282,30 +282,68 @@ def test_full_size_properties(full_sd):
 # ------------------------------------------------------------------------------------------------
 # Round 2: the evidence VERDICT r1 asked for — golden conditioning through the PRODUCT classes on the device,
 # BASELINE config 3's workload on one GPU (B = 13 plan == four padded shards), full-size kernels vs the oracle.
-def test_golden_conditioning_through_product_classes(golden_dir):
+def test_golden_conditioning_through_product_classes(hip, golden_dir):
     """tests/golden/conditioning.npz = outputs of the imported reference classes (oracle/make_golden.py).  Here the
-    product's ``conditioning.py`` classes produce them on the device: fp32 tolerance 2e-5 (+1e-5 relative)."""
+    product's ``conditioning.py`` classes produce them on the device THROUGH THE HIP KERNELS: the AOE path is fp32
+    (interpolation kernel + fp32-weight rows kernel): 2e-5 (+1e-5 relative); resampler, basic projection and
+    purifier run on the fp16-operand GEMM / attention kernels: 4e-3 (the tolerance of the golden cross-attention)."""
     from progressive_stable_diffusion_amd import conditioning as PC
     from progressive_stable_diffusion_amd import weights as W
     g = np.load(os.path.join(golden_dir, "conditioning.npz"))
     sd = W.init_state_dict(W.conditioning_shapes(), GI.SEED)
 
-    def close(got, key):
+    def close(got, key, atol, rtol):
         ref = torch.from_numpy(g[key])
         err = (got.float().cpu() - ref).abs()
-        assert got.shape == ref.shape and bool((err <= 2e-5 + 1e-5 * ref.abs()).all()), (key, err.max().item())
+        assert got.shape == ref.shape and bool((err <= atol + rtol * ref.abs()).all()), (key, err.max().item())
+        return err.max().item()
 
-    aoe = PC.AdditiveOrdinalEmbedder(sd, DEV)
+    aoe = PC.AdditiveOrdinalEmbedder(sd, DEV, be=hip)
     labels, source = torch.tensor(GI.LABELS, device=DEV), torch.tensor(GI.SOURCE, device=DEV)
-    close(aoe(labels), "aoe_forward")
-    close(aoe.get_negative_embedding(labels), "aoe_negative")
-    close(aoe.get_ordinal_delta_embedding(source, labels), "aoe_delta")
+    close(aoe(labels), "aoe_forward", 2e-5, 1e-5)
+    close(aoe.get_negative_embedding(labels), "aoe_negative", 2e-5, 1e-5)
+    close(aoe.get_ordinal_delta_embedding(source, labels), "aoe_delta", 2e-5, 1e-5)
     assert aoe.get_ordinal_delta_embedding(labels, labels).abs().max().item() == 0.0     # ordinal_embedder.py:254-255
-    pur = PC.FeaturePurifier(sd, DEV)
-    close(pur(GI.purifier_image_tokens().to(DEV), aoe(torch.tensor(GI.PUR_SOURCE, device=DEV))), "pur_out")
-    close(PC.ImageProjectionPlus(sd, DEV)(GI.clip_hidden().to(DEV)), "plus_out")
+    pur = PC.FeaturePurifier(sd, DEV, be=hip)
+    e1 = close(pur(GI.purifier_image_tokens().to(DEV), aoe(torch.tensor(GI.PUR_SOURCE, device=DEV))), "pur_out", 4e-3, 4e-3)
+    e2 = close(PC.ImageProjectionPlus(sd, DEV, be=hip)(GI.clip_hidden().to(DEV)), "plus_out", 4e-3, 4e-3)
     sd_b = W.init_state_dict(W.conditioning_shapes(projection_plus=False, purifier=False), GI.SEED)
-    close(PC.ImageProjection(sd_b, DEV)(GI.clip_embeds().to(DEV)), "basic_out")
+    e3 = close(PC.ImageProjection(sd_b, DEV, be=hip)(GI.clip_embeds().to(DEV)), "basic_out", 4e-3, 4e-3)
+    print(f"golden conditioning through HIP: purifier {e1:.2e} resampler {e2:.2e} basic {e3:.2e}")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("tiny", [False, True])
+def test_clip_tower_matches_transformers(hip, tiny):
+    """The CLIP vision tower on the HIP kernels (patch GEMM, LayerNorm-folded q|k|v and fc1 GEMMs, flash attention
+    d = 64, quick-GELU epilogue) vs ``transformers.CLIPVisionModelWithProjection`` — the reference's own encoder
+    (src/models/image_encoder.py:34-42) — in fp32 on the CPU with the same seeded weights: ViT-L/14 (24 layers, 257
+    tokens) and a 2-layer tower.  Tolerance 1e-2 of the largest value (fp16 rows through 24 residual layers)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from progressive_stable_diffusion_amd import conditioning as PC
+    from progressive_stable_diffusion_amd import weights as W
+    cfg = dict(TINY_CLIP) if tiny else dict(W.CLIP_VIT_L14)
+    sd = W.init_state_dict(W.clip_shapes(cfg), 5)
+    hf = CLIPVisionModelWithProjection(CLIPVisionConfig(**cfg)).eval()
+    pref = "image_encoder.image_encoder."
+    missing, unexpected = hf.load_state_dict({k[len(pref):]: v for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("position_ids") for k in missing), (missing, unexpected)
+    px = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        ref = hf(pixel_values=px, output_hidden_states=True)
+    enc = PC.ImageEncoder(sd, DEV, be=hip)
+    assert enc.cfg["num_hidden_layers"] == cfg["num_hidden_layers"] and enc.hidden_size == cfg["hidden_size"]
+    hs = enc.get_hidden_states(px.to(DEV))
+    emb = enc(px.to(DEV))
+    torch.cuda.synchronize()
+    eh = (hs.cpu() - ref.hidden_states[-1]).abs().max().item() / ref.hidden_states[-1].abs().max().item()
+    ee = (emb.cpu() - ref.image_embeds).abs().max().item() / ref.image_embeds.abs().max().item()
+    print(f"clip tower tiny={tiny}: hidden_states[-1] rel {eh:.3e}, image_embeds rel {ee:.3e}")
+    assert hs.shape == ref.hidden_states[-1].shape and eh < 1e-2 and ee < 1e-2
+    # one structure image expanded over the batch (inference_pipeline_ip.py:377-385): encoded once, same values
+    hs1 = enc.get_hidden_states(px[:1].to(DEV).expand(3, -1, -1, -1))
+    assert hs1.shape[0] == 3 and torch.equal(hs1[0], hs1[2]) and (hs1[0] - hs[0]).abs().max().item() < 2e-3 * ref.hidden_states[-1].abs().max().item()
 
 
 def test_config3_sweep_single_plan_and_four_shards(full_sd):
@@ -455,14 +493,12 @@ def test_main_cli_end_to_end(full_sd, tmp_path):
     from PIL import Image
     from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
     from progressive_stable_diffusion_amd import weights as W
-    from progressive_stable_diffusion_amd.conditioning import ImageEncoder
     from progressive_stable_diffusion_amd.config import default_config
     shapes = dict(W.unet_shapes())
     shapes.update(W.vae_shapes(encoder=False))
     shapes.update(W.conditioning_shapes(clip_hidden=TINY_CLIP["hidden_size"], clip_proj=TINY_CLIP["projection_dim"]))
     sd = W.init_state_dict(shapes, 0, gates=GI.GATES)
-    enc = ImageEncoder("cpu", seed=3, clip_config=TINY_CLIP)
-    sd.update({"image_encoder.image_encoder." + k: v for k, v in enc.image_encoder.state_dict().items()})
+    sd.update(W.init_state_dict(W.clip_shapes(TINY_CLIP), 3))
     torch.save({"state_dict": sd}, tmp_path / "last.ckpt")
 
     def plain(o):

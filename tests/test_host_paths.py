@@ -100,7 +100,7 @@ def test_sampler_with_leace_and_image_scale_matches_oracle(mod):
         got = PIPE._prepare_conditioning(mod, target, source, pix, image_scale=0.5, leace=leace)
         feats = mod.image_encoder.get_hidden_states(pix)
         ref = OS.prepare_conditioning(mod._sd, _ocfg(mod), target, source, feats, image_scale=0.5, leace=leace)
-    assert got.shape == (2, 48, 768) and (got - ref).abs().max().item() < 1e-4
+    assert got.shape == (2, 48, 768) and (got - ref).abs().max().item() < 8e-3      # image segment: fp16 rows
 
 
 # ------------------------------------------------------------------------------------------- eta > 0
@@ -134,9 +134,7 @@ def test_ddim_stochastic_matches_oracle(mod):
 
 # ------------------------------------------------------------------------------------------- checkpoints
 def _tiny_clip_sd():
-    from progressive_stable_diffusion_amd.conditioning import ImageEncoder
-    enc = ImageEncoder("cpu", seed=3, clip_config=TINY_CLIP)
-    return {"image_encoder.image_encoder." + k: v.clone() for k, v in enc.image_encoder.state_dict().items()}
+    return W.init_state_dict(W.clip_shapes(TINY_CLIP), 3)
 
 
 def _load(path, **kw):
@@ -183,8 +181,9 @@ def test_checkpoint_layouts_round_trip(full_sd, tmp_path):
         m = _load(p)
         assert m.load_report.missing == [] and torch.equal(m._sd["unet.unet.conv_in.weight"], sd["unet.unet.conv_in.weight"])
         # the CLIP tower came from the file, not from the seed
-        w = m.image_encoder.image_encoder.state_dict()["vision_model.embeddings.class_embedding"]
+        w = m.image_encoder.p["vision_model.embeddings.class_embedding"]
         assert torch.equal(w.cpu(), sd["image_encoder.image_encoder.vision_model.embeddings.class_embedding"])
+        assert m.image_encoder.cfg["hidden_size"] == 64 and m.image_encoder.layers == 2      # geometry from the tensors
     # same eps from the loaded module as from the in-memory one
     torch.manual_seed(4)
     x, t, c = torch.randn(1, 4, 8, 8), torch.tensor([300]), torch.randn(1, 48, 768) * 0.5

@@ -119,11 +119,18 @@ class TorchRefBackend:
             mu = xin.mean(dim=-1, keepdim=True)
             var = (xin * xin).mean(dim=-1, keepdim=True) - mu * mu
             y = torch.rsqrt(var.clamp_min(0.0) + ln_eps) * (y - mu * ln_c1.float())
+        act = flags & (256 | 512 | 1024)
         flags &= 15                     # tuning bits (16, 32) do not change the math
         if flags & EPI_BIAS:
             y = y + bias.float()
         if flags & EPI_ROWVEC:
             y = y + rowvec.float()[:, None, None, :]
+        if act & 256:
+            y = y * torch.sigmoid(1.702 * y)
+        elif act & 512:
+            y = F.gelu(y)
+        elif act & 1024:
+            y = torch.sigmoid(y)
         if flags & EPI_GEGLU:
             y = y[..., geglu_deinterleave_index(n).argsort()]   # undo the physical row order
             hid, gate = y.chunk(2, dim=-1)
@@ -187,9 +194,37 @@ class TorchRefBackend:
         out.copy_(torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1))
 
     def linear_rows(self, x, w, bias, out, act_in=0, act_out=0):
-        v = F.silu(x.float()) if act_in else x.float()
-        y = F.linear(v, w.float(), None if bias is None else bias.float())
-        out.copy_(F.silu(y) if act_out else y)
+        act = {0: lambda t: t, 1: F.silu, 2: F.gelu}
+        y = F.linear(act[act_in](x.float()), w.float(), None if bias is None else bias.float())
+        out.copy_(act[act_out](y))
+
+    def attention(self, q, k, v, out, heads):
+        b, nq, c = out.shape
+        d = c // heads
+        qh, kh, vh = (t[..., :c].float().reshape(b, t.shape[1], heads, d).transpose(1, 2) for t in (q, k, v))
+        p = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(d), dim=-1)
+        out.copy_((p @ vh).transpose(1, 2).reshape(b, nq, c).to(out.dtype))
+
+    def clip_patch_rows(self, pixels, out, patch):
+        b, _, h, w = pixels.shape
+        cols = F.unfold(pixels.float(), kernel_size=patch, stride=patch).transpose(1, 2)     # [B, T-1, 3*P*P]
+        out.zero_()
+        out[:, 1:, : cols.shape[-1]] = cols.to(out.dtype)
+
+    def aoe_interp(self, labels, base, deltas, out):
+        steps = torch.cumsum(deltas.float(), dim=0)
+        tab = base.float() + torch.cat([torch.zeros_like(steps[:1]), steps], dim=0)
+        top = tab.shape[0] - 1
+        y = labels.float().clamp(0.0, float(top))
+        lo = y.floor()
+        frac = (y - lo)[:, None]
+        lo_i = lo.long()
+        hi_i = (lo_i + 1).clamp(max=top)
+        out.copy_(tab[lo_i] * (1.0 - frac) + tab[hi_i] * frac)
+
+    def purifier_tail(self, img, dis, gate, gamma, beta, out, eps=1e-5):
+        v = img.float() - gate.float() * dis.float()
+        out.copy_(F.layer_norm(v, (v.shape[-1],), gamma.float(), beta.float(), eps).reshape(out.shape))
 
     def begin_step(self, table, cur_rows, coef, cur_coef, step):
         r = int(step.item())
