@@ -3,8 +3,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input per GPU:
 ``_ddim_sample_ip`` (conditioning prep + 50 hipGraph-replayed UNet/DDIM steps, delta steering
-lambda = 3.0) + ``_latents_to_images`` (VAE decode), then — for N > 1 — the single RCCL all-gather of
-decoded frames.  Workload = BASELINE.json configs[1] per rank (weak scaling: 4 images per GPU).
+lambda = 3.0) + ``_latents_to_images`` (VAE decode) + the uint8 pack of the frames, then — for N > 1 — the single
+RCCL all-gather of the decoded (uint8) frames.  Workload = BASELINE.json configs[1] per rank (weak scaling: 4 images per GPU).
 Weights are seeded random tensors of the SD-1.4 / DADD architecture (no checkpoints offline).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
@@ -212,7 +212,7 @@ def main():
             z = PIPE._ddim_sample_ip(mod, target, source, pix, a.ddim_steps, dev,
                                      steer_scale=a.steer_scale, latents=lat)
             frames = PIPE._latents_to_images(mod, z)
-            return D.all_gather_frames(frames)
+            return D.all_gather_frames_u8(mod.be, frames)      # uint8 NHWC frames: what the writers consume
 
     for _ in range(a.warmup):
         one_pass()
@@ -225,7 +225,7 @@ def main():
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
-    assert frames.shape == (n_total, 3, a.image_size, a.image_size)
+    assert frames.shape == (n_total, a.image_size, a.image_size, 3) and frames.dtype == torch.uint8
 
     roof = None
     if not a.no_roofline:
@@ -242,7 +242,7 @@ def main():
             "config": {"workload": f"{a.image_size}x{a.image_size}, {a.ddim_steps} DDIM steps, bs={a.batch}/GPU, "
                                    f"delta-steer lambda={a.steer_scale}, routing gates on, conditioning prep + "
                                    "VAE decode included", "global_batch": n_total,
-                       "parallelism": f"batch-shard x{world} + 1 all-gather of frames"},
+                       "parallelism": f"batch-shard x{world} + 1 all-gather of uint8 frames"},
             "achieved_tflops_whole_job": value * FLOP_PER_IMAGE / 1e12 if a.image_size == 512 else None,
             "frac_of_mfma_peak_whole_job": (value * FLOP_PER_IMAGE / 1e12) / (PEAK_F16_TFLOPS * world)
             if a.image_size == 512 else None,

@@ -115,6 +115,11 @@ int dadd_pack_nchw_f32_to_nhwc8_f16(const float* x, void* out, int B, int C, int
 int dadd_gaussian_sample_f32(const float* mean, const float* logvar, const float* noise, float scale,
                              float* out, int64_t n, void* stream);
 
+/* Decoded frames fp32 NCHW in [0,1] -> uint8 NHWC (v * 255 truncated = ``.mul(255).to(torch.uint8)`` of
+ * _tensor_to_bmp / _save_sequence, src/pipelines/inference/inference_pipeline_ip_data_augment.py:136-140,
+ * inference_pipeline_ip.py:489-510): 4x fewer bytes over PCIe to the writers and over xGMI in the frame gather. */
+int dadd_frames_to_u8(const float* frames_nchw, void* out_nhwc_u8, int B, int H, int W, void* stream);
+
 /* ---- normalisation -------------------------------------------------------------------------
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
  * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats.

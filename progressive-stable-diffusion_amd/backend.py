@@ -97,6 +97,11 @@ class HipBackend:
         L.check(self.lib.dadd_conv3x3_cout4_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, c, co,
                                                 int(mode), self.s))
 
+    def frames_to_u8(self, frames, out):
+        b, c, h, w = frames.shape
+        assert c == 3 and frames.dtype == torch.float32 and out.dtype == torch.uint8 and out.shape == (b, h, w, 3)
+        L.check(self.lib.dadd_frames_to_u8(_p(frames), _p(out), b, h, w, self.s))
+
     def gaussian_sample(self, mean, logvar, noise, out, scale=1.0):
         assert mean.shape == logvar.shape == noise.shape == out.shape and mean.dtype == torch.float32
         L.check(self.lib.dadd_gaussian_sample_f32(_p(mean), _p(logvar), _p(noise), float(scale), _p(out),

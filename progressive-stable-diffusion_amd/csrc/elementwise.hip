@@ -248,7 +248,45 @@ __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __res
   }
 }
 
+// frames fp32 NCHW in [0, 1] -> uint8 NHWC (what PIL / the BMP writers take): v * 255 truncated, exactly
+// ``tensor.permute(1, 2, 0).mul(255).to(torch.uint8)`` of the reference's writers.  One thread = 4 pixels x 3 channels
+// = three packed 32-bit stores of 12 contiguous bytes.
+__global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int B,
+                                                        int HW) {
+  const size_t quads = (size_t)B * (HW / 4);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / (HW / 4), q = i - b * (HW / 4);
+    const float* src = x + b * 3 * HW + q * 4;
+    const f4 r = *reinterpret_cast<const f4*>(src), g = *reinterpret_cast<const f4*>(src + HW),
+             bl = *reinterpret_cast<const f4*>(src + 2 * (size_t)HW);
+    uint8_t px[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      px[3 * k] = (uint8_t)(r[k] * 255.0f);
+      px[3 * k + 1] = (uint8_t)(g[k] * 255.0f);
+      px[3 * k + 2] = (uint8_t)(bl[k] * 255.0f);
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + (b * HW + q * 4) * 3);
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      dst[w] = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
+  }
+}
+
 }  // namespace
+
+extern "C" int dadd_frames_to_u8(const float* frames_nchw, void* out_nhwc_u8, int B, int H, int W, void* stream) {
+  DADD_REQUIRE(frames_nchw && out_nhwc_u8 && B > 0 && H > 0 && W > 0 && (H * W) % 4 == 0,
+               "frames_to_u8: H*W must be a multiple of 4");
+  DADD_REQUIRE(dadd_aligned16(frames_nchw) && (((uintptr_t)out_nhwc_u8) & 3) == 0, "frames_to_u8: alignment");
+  const size_t quads = (size_t)B * (H * W / 4);
+  int blocks = (int)((quads + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  dadd_launch({"frames_u8_kernel", 0.0, (double)B * H * W * 15.0}, frames_u8_kernel, dim3(blocks), dim3(256), 0,
+              static_cast<hipStream_t>(stream), frames_nchw, static_cast<uint8_t*>(out_nhwc_u8), B, H * W);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
 
 extern "C" int dadd_gaussian_sample_f32(const float* mean, const float* logvar, const float* noise, float scale,
                                         float* out, int64_t n, void* stream) {

@@ -35,8 +35,11 @@ def _worker(rank, world, port, n_labels, per_rank, out_dir):
     frames = _fake_frames(loc, lat)
     D.barrier()
     allf = D.all_gather_frames(frames, n_total=n_labels)
+    from tests.torch_backend import TorchRefBackend
+    unit = (frames - frames.min()) / (frames.max() - frames.min() + 1e-6)        # [0,1] frames for the uint8 gather
+    all8 = D.all_gather_frames_u8(TorchRefBackend(), unit.expand(-1, -1, 2, 2).contiguous(), n_total=n_labels)
     t = D.max_over_ranks(1.0 + rank)
-    torch.save({"frames": allf, "t": t, "n_valid": n_valid, "lat": lat}, f"{out_dir}/r{rank}.pt")
+    torch.save({"frames": allf, "u8": all8, "t": t, "n_valid": n_valid, "lat": lat}, f"{out_dir}/r{rank}.pt")
     dist.destroy_process_group()
 
 
@@ -51,6 +54,8 @@ def test_two_rank_sweep_equals_single_process(tmp_path, n_labels, per_rank):
         assert torch.equal(o["lat"], lat)                       # every rank starts from the same noise
         assert o["frames"].shape == (n_labels, 3, 2, 2)
         assert torch.equal(o["frames"], expect)                 # shard -> gather == single process
+        assert o["u8"].shape == (n_labels, 2, 2, 3) and o["u8"].dtype == torch.uint8
+        assert torch.equal(o["u8"], outs[0]["u8"])              # every rank holds the same gathered uint8 frames
         assert o["t"] == 2.0                                    # MAX over ranks
     assert sum(o["n_valid"] for o in outs) == n_labels
 

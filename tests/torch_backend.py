@@ -90,6 +90,9 @@ class TorchRefBackend:
             y = y.clamp(-30.0, 20.0)
         out.copy_(y)
 
+    def frames_to_u8(self, frames, out):
+        out.copy_(frames.permute(0, 2, 3, 1).mul(255).to(torch.uint8))
+
     def gaussian_sample(self, mean, logvar, noise, out, scale=1.0):
         out.copy_((mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise) * scale)
 
