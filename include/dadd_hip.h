@@ -120,6 +120,14 @@ int dadd_gaussian_sample_f32(const float* mean, const float* logvar, const float
  * inference_pipeline_ip.py:489-510): 4x fewer bytes over PCIe to the writers and over xGMI in the frame gather. */
 int dadd_frames_to_u8(const float* frames_nchw, void* out_nhwc_u8, int B, int H, int W, void* stream);
 
+/* ---- training-step forward (loss evaluation; src/models/diffusion_module_ip.py:392-462) ----------------------
+ * x_t = sqrt(ab[t_b]) x0 + sqrt(1 - ab[t_b]) noise (``_q_sample`` :299-303), per-sample int64 timesteps. */
+int dadd_q_sample_f32(const float* x0, const float* noise, const int64_t* t, const float* alphas_cumprod,
+                      float* out, int B, int64_t per_sample, void* stream);
+/* out[b] = mean_i (pred[b][i] - target[b][i])^2  (F.mse_loss(reduction="none").mean(dim=(1,2,3)), :440-441). */
+int dadd_mse_rows_f32(const float* pred, const float* target, float* out, int B, int64_t per_sample,
+                      void* stream);
+
 /* ---- normalisation -------------------------------------------------------------------------
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
  * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats.

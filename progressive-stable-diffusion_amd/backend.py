@@ -97,6 +97,17 @@ class HipBackend:
         L.check(self.lib.dadd_conv3x3_cout4_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, c, co,
                                                 int(mode), self.s))
 
+    def q_sample(self, x0, noise, t, alphas_cumprod, out):
+        b = x0.shape[0]
+        assert x0.dtype == torch.float32 and t.dtype == torch.int64 and t.shape == (b,) and noise.shape == x0.shape
+        L.check(self.lib.dadd_q_sample_f32(_p(x0), _p(noise), _p(t), _p(alphas_cumprod), _p(out), b,
+                                           x0.numel() // b, self.s))
+
+    def mse_rows(self, pred, target, out):
+        b = pred.shape[0]
+        assert pred.shape == target.shape and out.shape == (b,) and pred.dtype == torch.float32
+        L.check(self.lib.dadd_mse_rows_f32(_p(pred), _p(target), _p(out), b, pred.numel() // b, self.s))
+
     def frames_to_u8(self, frames, out):
         b, c, h, w = frames.shape
         assert c == 3 and frames.dtype == torch.float32 and out.dtype == torch.uint8 and out.shape == (b, h, w, 3)

@@ -273,7 +273,63 @@ __global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict_
   }
 }
 
+// Forward diffusion (src/models/diffusion_module_ip.py:299-303): x_t = sqrt(ab[t_b]) x0 + sqrt(1 - ab[t_b]) noise,
+// per-sample timestep; fp32, individually rounded ops in the reference's order.
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const int64_t* __restrict__ t, const float* __restrict__ ab,
+                                                       float* __restrict__ out, int B, int64_t per) {
+#pragma clang fp contract(off)
+  const int64_t n = (int64_t)B * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = ab[t[i / per]];
+    const float s0 = sqrtf(a), s1 = sqrtf(1.0f - a);
+    const float u = s0 * x0[i];
+    const float v = s1 * noise[i];
+    out[i] = u + v;
+  }
+}
+
+// base_loss[b] = mean over the sample of (pred - target)^2 (F.mse_loss(reduction="none").mean(dim=(1,2,3)),
+// diffusion_module_ip.py:440-441): one block per sample, fixed-order tree (bit-reproducible).
+__global__ __launch_bounds__(256) void mse_rows_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       float* __restrict__ out, int64_t per) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* p = pred + (size_t)b * per;
+  const float* q = target + (size_t)b * per;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += 256) {
+    const float d = p[i] - q[i];
+    acc += d * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (red[0] + red[1] + red[2] + red[3]) / (float)per;
+}
+
 }  // namespace
+
+extern "C" int dadd_q_sample_f32(const float* x0, const float* noise, const int64_t* t, const float* alphas_cumprod,
+                                 float* out, int B, int64_t per_sample, void* stream) {
+  DADD_REQUIRE(x0 && noise && t && alphas_cumprod && out && B > 0 && per_sample > 0, "q_sample: bad arguments");
+  const int64_t n = (int64_t)B * per_sample;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  dadd_launch({"q_sample_kernel", 0.0, (double)n * 12.0}, q_sample_kernel, dim3(blocks), dim3(256), 0,
+              static_cast<hipStream_t>(stream), x0, noise, t, alphas_cumprod, out, B, per_sample);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+extern "C" int dadd_mse_rows_f32(const float* pred, const float* target, float* out, int B, int64_t per_sample,
+                                 void* stream) {
+  DADD_REQUIRE(pred && target && out && B > 0 && per_sample > 0, "mse_rows: bad arguments");
+  dadd_launch({"mse_rows_kernel", 0.0, (double)B * per_sample * 8.0}, mse_rows_kernel, dim3(B), dim3(256), 0,
+              static_cast<hipStream_t>(stream), pred, target, out, per_sample);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
 
 extern "C" int dadd_frames_to_u8(const float* frames_nchw, void* out_nhwc_u8, int B, int H, int W, void* stream) {
   DADD_REQUIRE(frames_nchw && out_nhwc_u8 && B > 0 && H > 0 && W > 0 && (H * W) % 4 == 0,

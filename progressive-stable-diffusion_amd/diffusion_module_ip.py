@@ -434,6 +434,78 @@ class DiffusionModuleWithIP:
             feats = self.image_encoder(structure_images)
         return self.image_projection(feats)
 
+    # ---- training-step forward (src/models/diffusion_module_ip.py:289-462) -----------------------------------------
+    def _sample_timesteps(self, batch_size: int) -> torch.Tensor:
+        """(:289-297)"""
+        return torch.randint(0, self.diff_cfg.num_train_timesteps, (batch_size,), device=self.device, dtype=torch.long)
+
+    def _q_sample(self, x0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """(:299-303) forward diffusion on the HIP kernel."""
+        be = self.be
+        x0, noise = x0.float().contiguous(), noise.float().contiguous()
+        t = t.to(device=self.device, dtype=torch.long).contiguous()
+        be.wait_current()
+        out = be.empty(tuple(x0.shape), torch.float32)
+        be.q_sample(x0, noise, t, self.alphas_cumprod, out)
+        be.release_to_current()
+        return out
+
+    def _min_snr_weight(self, t: torch.Tensor) -> torch.Tensor:
+        """(:305-313) Min-SNR-gamma weight per sample."""
+        if not getattr(self.cfg.training, "use_min_snr_weighting", True):
+            return torch.ones_like(t, dtype=torch.float32, device=self.device)
+        snr = self.snr_values[t]
+        return torch.minimum(snr, torch.tensor(self.diff_cfg.min_snr_gamma, device=snr.device)) / (snr + 1e-8)
+
+    def _prepare_conditioning(self, labels, structure_images, is_training: bool = True):
+        """(:334-381) training-time conditioning: source == target label, delta segment exactly zero."""
+        aoe = self.ordinal_embedder(labels, is_training=is_training)
+        if aoe.dim() == 2:
+            aoe = aoe.unsqueeze(1)
+        img = self._get_image_embeds(structure_images)
+        if self.feature_purifier is not None:
+            img = self.feature_purifier(img, aoe)
+        if self.diff_cfg.use_routing_gates:
+            return aoe, img, torch.zeros_like(aoe)
+        return aoe, img
+
+    def training_step(self, batch, batch_idx: int = 0, *, noise=None, t=None, drop_mask=None, latent_noise=None,
+                      is_training: bool = True):
+        """FORWARD half of ``training_step`` (:392-462): VAE encode -> latent sample x latent_scale -> q_sample ->
+        conditioning (is_training noise on the AOE interpolation, CFG image-token dropout) -> eps prediction -> per-sample
+        MSE x Min-SNR weight -> mean.  Returns the loss VALUE (a tensor without autograd history): the backward
+        kernels, AdamW and EMA of BASELINE config 4 are not built, so ``loss.backward()`` raises as any leaf without
+        grad does.  Keyword-only extras inject the random draws (parity tests): ``noise`` (eps), ``t``, ``drop_mask``,
+        ``latent_noise`` (the VAE posterior draw); ``is_training=False`` switches the AOE's own interpolation noise off."""
+        images, labels, structure_images = batch
+        b = images.shape[0]
+        dist = self.vae.encode(images).latent_dist
+        latents = dist.sample(noise=latent_noise, scale=self.diff_cfg.latent_scale)
+        if noise is None:
+            noise = torch.randn_like(latents)
+        noise = noise.to(device=self.device, dtype=torch.float32)
+        if t is None:
+            t = self._sample_timesteps(b)
+        t = t.to(self.device)
+        noisy = self._q_sample(latents, t, noise)
+        parts = self._prepare_conditioning(labels, structure_images, is_training=is_training)
+        aoe, img = parts[0], parts[1]
+        if drop_mask is None:
+            drop_mask = torch.rand(b, device=self.device) < getattr(self.cfg.model, "cfg_drop_prob", 0.1)
+        img = torch.where(drop_mask.to(self.device).view(-1, 1, 1).expand_as(img), torch.zeros_like(img), img)
+        cond = torch.cat([aoe, img, parts[2]] if self.diff_cfg.use_routing_gates else [aoe, img], dim=1)
+        pred = self(noisy, t, cond)
+        be = self.be
+        be.wait_current()
+        base = be.empty((b,), torch.float32)
+        be.mse_rows(pred.contiguous(), noise.contiguous(), base)
+        be.release_to_current()
+        return (self._min_snr_weight(t) * base).mean()
+
+    def configure_optimizers(self):
+        raise NotImplementedError("training (backward kernels, fused AdamW, EMA: BASELINE config 4 / SURVEY.md §8f-4) is not "
+                                  "built; training_step() evaluates the loss only")
+
     def __call__(self, latents: torch.Tensor, timesteps: torch.Tensor, cond_embed: torch.Tensor):
         b, _, s, _ = latents.shape
         u = self._unet_for(b, s)

@@ -45,6 +45,8 @@ PROTOTYPES = {
                                          C.c_int, vp]),
     "dadd_pack_nchw_f32_to_nhwc8_f16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp,
                                                   vp, vp]),
+    "dadd_q_sample_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, i64, vp]),
+    "dadd_mse_rows_f32": (C.c_int, [vp, vp, vp, C.c_int, i64, vp]),
     "dadd_frames_to_u8": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_gaussian_sample_f32": (C.c_int, [vp, vp, vp, f32, vp, i64, vp]),
     "dadd_groupnorm_f16": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,

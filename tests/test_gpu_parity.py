@@ -643,3 +643,32 @@ def test_generation_drivers_and_frame_sink_on_device(full_sd, tmp_path):
     for k in range(6):
         got = torch.from_numpy(np.asarray(Image.open(tmp_path / "s" / f"{k}.png")).copy()).permute(2, 0, 1)
         assert torch.equal(got, fr[k].mul(255).to(torch.uint8))
+
+
+def test_training_step_forward_on_device(full_sd):
+    """BASELINE config 4's forward half at 128x128, B = 2 on the HIP kernels (VAE encode, posterior sample, q_sample,
+    conditioning with CFG image dropout, UNet eps, eps-MSE x Min-SNR) vs ``oracle.training`` with every draw injected.
+    Tolerance 2 % of the loss (fp16 storage through encoder + UNet).  The backward pass / AdamW are not built."""
+    from oracle import training as OT
+    from progressive_stable_diffusion_amd import weights as W
+    sd = dict(full_sd)
+    sd.update(W.init_state_dict(W.vae_shapes(decoder=False), 0))
+    mod = _module(sd, 128, 2)
+    g = torch.Generator().manual_seed(31)
+    images = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    labels = torch.tensor([1.0, 3.0])
+    pix = torch.randn(2, 3, 224, 224, generator=g)
+    t = torch.tensor([700, 35])
+    noise, lat_noise = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g)
+    drop = torch.tensor([False, True])
+    with torch.no_grad():
+        loss = mod.training_step((images.to(DEV), labels.to(DEV), pix.to(DEV)), 0, noise=noise, t=t, drop_mask=drop,
+                                 latent_noise=lat_noise, is_training=False)
+        feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
+        ref, _ = OT.training_loss(sd, _ocfg(mod), images, labels, feats, t, noise, lat_noise, drop)
+    print(f"training-step forward: loss {loss.item():.6f} vs oracle {ref.item():.6f}")
+    assert abs(loss.item() - ref.item()) < 2e-2 * max(1.0, abs(ref.item()))
+    x0 = torch.randn(2, 4, 16, 16, generator=g)
+    assert torch.equal(mod._q_sample(x0.to(DEV), t, noise).cpu(), OT.q_sample(mod.alphas_cumprod.cpu(), x0, t, noise))
+    l2 = mod.training_step((images.to(DEV), labels.to(DEV), pix.to(DEV)))            # device RNG everywhere: finite
+    assert torch.isfinite(l2) and l2.item() > 0.0

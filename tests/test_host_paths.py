@@ -312,3 +312,58 @@ def test_seed_and_device_helpers():
     assert torch.equal(a, torch.rand(3))
     args = PIPE._parse_args(["--checkpoint", "c.ckpt", "--structure-image", "s.png"])
     assert args.mes_steps == 13 and args.sampling_steps == 50 and args.steer_scale == 0.0 and args.eta == 0.0
+
+
+# ------------------------------------------------------------------------------------------- training-step forward
+def test_training_step_forward_matches_oracle(full_sd):
+    """The forward half of ``training_step`` (diffusion_module_ip.py:392-462) through the engine (torch test backend)
+    vs ``oracle.training``: VAE encode + posterior sample, q_sample, training-time conditioning with a zero delta
+    segment, CFG image-token dropout, eps-MSE x Min-SNR.  Every random draw is injected."""
+    from oracle import training as OT
+    sd = dict(full_sd)
+    sd.update(W.init_state_dict(W.vae_shapes(decoder=False), 0))
+    cfg = default_config(**{"dataset.image_size": 64})
+    with pytest.warns(RuntimeWarning):
+        m = DiffusionModuleWithIP(cfg, state_dict=sd, device="cpu", batch_size=2, clip_config=TINY_CLIP, backend=TorchRefBackend())
+    g = torch.Generator().manual_seed(31)
+    images = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    labels = torch.tensor([1.0, 3.0])
+    pix = torch.randn(2, 3, 224, 224, generator=g)
+    t = torch.tensor([700, 35])
+    noise, lat_noise = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    drop = torch.tensor([False, True])
+    with torch.no_grad():
+        loss = m.training_step((images, labels, pix), 0, noise=noise, t=t, drop_mask=drop, latent_noise=lat_noise, is_training=False)
+        feats = m.image_encoder.get_hidden_states(pix)
+        ref, base = OT.training_loss(m._sd, _ocfg(m), images, labels, feats, t, noise, lat_noise, drop)
+    assert loss.shape == () and not loss.requires_grad
+    assert abs(loss.item() - ref.item()) < 2e-2 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    with pytest.raises(RuntimeError):
+        loss.backward()                                     # no autograd history: the backward pass is not built
+    with pytest.raises(NotImplementedError):
+        m.configure_optimizers()
+    # pieces: q_sample and the Min-SNR weight against their restatements, known answers of App. C
+    x0 = torch.randn(2, 4, 8, 8, generator=g)
+    assert torch.allclose(m._q_sample(x0, t, noise), OT.q_sample(m.alphas_cumprod, x0, t, noise), atol=1e-6)
+    w = m._min_snr_weight(torch.tensor([999, 0]))
+    assert w[0].item() == pytest.approx(1.0, abs=1e-5)      # snr[999] = 0.00158 < gamma = 1 -> clipped / snr = 1
+    assert w[1].item() == pytest.approx(1.0 / (0.999149978 / (1 - 0.999149978 + 1e-8)), rel=1e-3)
+    assert m._sample_timesteps(5).shape == (5,) and m._sample_timesteps(5).dtype == torch.long
+    parts = m._prepare_conditioning(labels, pix, is_training=False)
+    assert len(parts) == 3 and float(parts[2].abs().max()) == 0.0 and parts[1].shape == (2, 16, 768)
+
+
+def test_warmup_cosine_schedule_known_answers():
+    from oracle import training as OT
+    from progressive_stable_diffusion_amd.lr_scheduler import warmup_cosine_lr
+    kw = dict(warmup_epochs=2, max_epochs=150, warmup_start_lr=1e-6, eta_min=1e-6)       # configs/train_ip.yaml:45-56
+    base = [1e-4, 1e-4, 2e-4, 2e-4]                                                       # four parameter groups (:500-515)
+    assert warmup_cosine_lr(0, base, **kw) == pytest.approx([1e-6] * 4)
+    assert warmup_cosine_lr(1, base, **kw) == pytest.approx([(1e-6 + 1e-4) / 2] * 2 + [(1e-6 + 2e-4) / 2] * 2)
+    assert warmup_cosine_lr(2, base, **kw) == pytest.approx(base)
+    assert warmup_cosine_lr(150, base, **kw) == pytest.approx([1e-6] * 4)
+    assert warmup_cosine_lr(400, base, **kw) == pytest.approx([1e-6] * 4)
+    mid = warmup_cosine_lr(76, base, **kw)
+    assert mid[0] == pytest.approx(1e-6 + (1e-4 - 1e-6) * 0.5, rel=1e-9)
+    for e in (0, 1, 5, 76, 149, 150):
+        assert warmup_cosine_lr(e, base, **kw) == pytest.approx(OT.warmup_cosine_lr(e, base, **kw))

@@ -90,6 +90,13 @@ class TorchRefBackend:
             y = y.clamp(-30.0, 20.0)
         out.copy_(y)
 
+    def q_sample(self, x0, noise, t, alphas_cumprod, out):
+        a = alphas_cumprod[t].view(-1, 1, 1, 1)
+        out.copy_(torch.sqrt(a) * x0 + torch.sqrt(1.0 - a) * noise)
+
+    def mse_rows(self, pred, target, out):
+        out.copy_(((pred - target) ** 2).mean(dim=tuple(range(1, pred.dim()))))
+
     def frames_to_u8(self, frames, out):
         out.copy_(frames.permute(0, 2, 3, 1).mul(255).to(torch.uint8))
 
