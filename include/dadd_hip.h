@@ -38,6 +38,9 @@ extern "C" {
 #define DADD_EPI_LNFOLD 128 /* a LayerNorm over the K (= channel) axis of x folded into this linear: w carries gamma,
                               bias the composed (w beta + b), ln_c1[n] = sum_k w[n][k]; the kernel derives the row
                               mean / rstd from the A fragments it reads anyway: out = rstd (acc - mu c1) + bias */
+#define DADD_EPI_GNSTAT 2048 /* the epilogue also writes the GroupNorm chunk partials of its OUTPUT (32 groups) into
+                               gn_ws [B][gn_nchunk][32][2] (sum, sum of squares per row block of tile_m/2 rows): the
+                               consuming dadd_groupnorm_f16 then skips its statistics pass (ws_chunks = gn_nchunk) */
 #define DADD_EPI_QUICKGELU 256 /* x * sigmoid(1.702 x) after bias (CLIP MLP, transformers quick_gelu) */
 #define DADD_EPI_GELU 512      /* exact-form GELU after bias (nn.GELU of the resampler / purifier MLPs) */
 #define DADD_EPI_SIGMOID 1024  /* sigmoid after bias (FeaturePurifier gate) */
@@ -90,6 +93,8 @@ typedef struct {
   const float* ln_c1;            /* DADD_EPI_LNFOLD: N floats (see the flag); replaces nn.LayerNorm + nn.Linear of
                                     BasicTransformerBlock.norm1/2/3 -> attn1.to_q|k|v / attn2.to_q / ff.net.0.proj */
   float ln_eps;
+  float* gn_ws;                  /* DADD_EPI_GNSTAT (see the flag) */
+  int32_t gn_nchunk, gn_cg;      /*   chunks per sample = Ho*Wo / (tile_m/2); channels per group = N / 32 */
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 
@@ -130,12 +135,14 @@ int dadd_mse_rows_f32(const float* pred, const float* target, float* out, int B,
 
 /* ---- normalisation -------------------------------------------------------------------------
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
- * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats.
+ * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats; with ws_chunks > 0 it already
+ * holds [B][ws_chunks][groups][2] partials written by the producing GEMM's epilogue (DADD_EPI_GNSTAT; x2 == NULL,
+ * ws_chunks <= 64) and the statistics pass is skipped.
  * Replaces nn.GroupNorm(+F.silu) in ResnetBlock2D / Transformer2DModel / VAE (+ torch.cat). */
 #define DADD_GN_MAX_CHUNKS 256
 int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,
                        const float* beta, void* out, float* ws, int B, int HW, int groups,
-                       float eps, int silu, void* stream);
+                       float eps, int silu, int ws_chunks, void* stream);
 /* LayerNorm over the last dim of [M][C] fp16 (BasicTransformerBlock.norm1/2/3). */
 int dadd_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int M,
                        int C, float eps, void* stream);

@@ -120,7 +120,7 @@ class HipBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0):
         """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU)."""
         b, hi, wi, c1 = x.shape
         c2 = 0 if x2 is None else x2.shape[-1]
@@ -138,20 +138,24 @@ class HipBackend:
         d.splitk, d.flags, d.tile_n, d.tile_m = splitk, flags, tile_n, tile_m
         d.counters = _p(counters)
         d.ln_c1, d.ln_eps = _p(ln_c1), float(ln_eps)
+        d.gn_ws, d.gn_nchunk, d.gn_cg = _p(gn_ws), int(gn_nchunk), (n // 32 if gn_ws is not None else 0)
+        if gn_ws is not None:
+            assert flags & L.EPI_GNSTAT and gn_ws.numel() >= b * gn_nchunk * 64 and gn_ws.dtype == torch.float32
         if ln_c1 is not None:
             assert flags & L.EPI_LNFOLD and ln_c1.numel() == n and ln_c1.dtype == torch.float32
         if partial is not None:
             assert partial.numel() >= splitk * b * ho * wo * n
         L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))
 
-    def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu):
+    def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu, ws_chunks=0):
+        """``ws_chunks`` > 0: ``ws`` holds the chunk partials written by the producing GEMM's epilogue."""
         b = x1.shape[0]
         hw = x1.shape[1] * x1.shape[2]
         c1 = x1.shape[-1]
         c2 = 0 if x2 is None else x2.shape[-1]
-        assert out.shape[-1] == c1 + c2 and ws.numel() >= b * L.GN_MAX_CHUNKS * groups * 2
+        assert out.shape[-1] == c1 + c2 and ws.numel() >= b * (ws_chunks or L.GN_MAX_CHUNKS) * groups * 2
         L.check(self.lib.dadd_groupnorm_f16(_p(x1), c1, _p(x2), c2, _p(gamma), _p(beta), _p(out),
-                                            _p(ws), b, hw, groups, float(eps), int(silu), self.s))
+                                            _p(ws), b, hw, groups, float(eps), int(silu), int(ws_chunks), self.s))
 
     def layernorm(self, x, gamma, beta, out, eps=1e-5):
         c = x.shape[-1]

@@ -51,7 +51,8 @@ constexpr int W_RING = 4 * B_BYTES;
 constexpr int HALO_MAX_PIX = 272;                  // >= (R+2)*(W+2) for W in {16, 32, 64}; 34 pieces of 8 pixels
 constexpr int HALO_BYTES = HALO_MAX_PIX * 128;
 constexpr int DUMP_OFF = W_RING + 2 * HALO_BYTES;
-constexpr int SMEM_BYTES = DUMP_OFF + 4 * 1024;
+constexpr int GN_OFF = DUMP_OFF + 4 * 1024;        // statistics scratch of the epilogue (igemm_epilogue.h)
+constexpr int SMEM_BYTES = GN_OFF + 4 * 1024;
 constexpr bool DO_LOAD = DADD_IGEMM_EXP != 5 && DADD_IGEMM_EXP != 6;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     o[0] = sc_bar; o[1] = sc_h0; o[2] = sc_h1; o[3] = __builtin_amdgcn_s_memtime() - c_begin;
   }
 #endif
-  igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
+  igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + GN_OFF);
 #endif
 }
 

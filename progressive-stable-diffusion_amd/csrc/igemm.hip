@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     ln_finish<MI>(ls1, ls2, p.K, p.ln_eps);
     igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, ls1, ls2);
   } else {
-    igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem);
+    igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + 2 * (BM + BN) * BK * 2);
   }
 }
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
 
 template <int BM, int BN, bool DEEP, bool LNF>
 int set_attr1() {
-  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
+  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;
   DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP, LNF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
@@ -255,7 +255,7 @@ int set_attr() {
 
 template <int BM, int BN, bool DEEP, bool LNF>
 int launch1(const IgemmArgs& a, int nsplit, hipStream_t s) {
-  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t);
+  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;   // + the epilogue's statistics scratch
   const int mtiles = (a.M + BM - 1) / BM;
   dim3 grid(mtiles * a.ntiles, nsplit);
   static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " +
@@ -306,7 +306,10 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK);   // epilogue bits + the persistent-ring request
+  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK | DADD_EPI_GNSTAT);
+  a.gn_ws = d->gn_ws;
+  a.gn_nchunk = d->gn_nchunk;
+  a.gn_cg = d->gn_cg;   // epilogue bits + the persistent-ring request
   a.ln_c1 = d->ln_c1;
   a.ln_eps = d->ln_eps;
   const int Cin = a.C1 + a.C2;
@@ -379,6 +382,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // consecutive K tiles — measured no different: the DMA stream is bound by the L2->LDS fill rate of a CU, not by
   // L1 hits: profiles/r01_x_dma_limits.txt.)
   a.korder = 0;
+  if (a.flags & DADD_EPI_GNSTAT) {
+    const int wm_rows = tile_m / 2, wn_cols = tile_n / 2, howo = a.Ho * a.Wo;
+    DADD_REQUIRE(a.gn_ws && a.gn_cg > 0 && a.N == 32 * a.gn_cg && !geglu && nsplit == 1 && (tile_n == 128 || tile_n == 160) &&
+                     wn_cols % a.gn_cg == 0 && a.M % tile_m == 0 && a.N % tile_n == 0 && howo % wm_rows == 0 &&
+                     a.gn_nchunk == howo / wm_rows && !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
+                 "igemm: GroupNorm statistics need full tiles of 128/160 columns holding whole groups, whole-wave row blocks "
+                 "inside one sample (Ho*Wo %% %d == 0, gn_nchunk == Ho*Wo / %d), N == 32 groups, no split-K", wm_rows, wm_rows);
+  }
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)

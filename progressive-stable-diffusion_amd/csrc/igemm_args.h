@@ -12,6 +12,8 @@ struct IgemmArgs {
   const float* rowvec;
   const half_t* residual;
   int* counters;   // split-K tickets, one per output tile, zero between launches (nullptr: finish kernel)
+  float* gn_ws;         // DADD_EPI_GNSTAT: GroupNorm chunk partials [B][gn_nchunk][32][2] written by the epilogue
+  int gn_nchunk, gn_cg;  //   chunks per sample (= Ho*Wo / rows per MFMA wave), channels per group
   const float* ln_c1;   // DADD_EPI_LNFOLD: c1[n] = sum_k w[n][k] (w already carries the LayerNorm gamma)
   float ln_eps;
   int B, Hi, Wi, C1, C2, Ho, Wo, N;

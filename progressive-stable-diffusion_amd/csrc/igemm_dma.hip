@@ -351,14 +351,14 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
       ln_finish<MI>(ls1, ls2, p.K, p.ln_eps);
       igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem, ls1, ls2);
     } else {
-      igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem);
+      igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem, nullptr, nullptr, smem + 4 * STAGE);
     }
   }
 #endif
 }
 
 template <int BM, int BN>
-constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2; }
+constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2 + 4096; }   // ring + the epilogue's statistics scratch
 
 template <int BM, int BN, bool UPS, bool PERS, bool LNF>
 int set_attr() {

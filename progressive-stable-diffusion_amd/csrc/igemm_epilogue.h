@@ -12,11 +12,23 @@
 #pragma once
 #include "igemm_args.h"
 
+// sum over the 16 lanes of a DPP row (all 16 end up with the total): xor 1, xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float dadd_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 // `ln_mu` / `ln_rs` (MI values each, or nullptr): row mean and 1/std of the folded LayerNorm (igemm_args.h).
+// `gn_scratch`: 4 KB of LDS (4 MFMA waves x [80 columns][2] floats) that no LDS-DMA can still be writing when the
+// epilogue runs — the staging area of the GroupNorm statistics (DADD_EPI_GNSTAT).
 template <int J, int MI, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][MI], int m0, int n0,
                                                int wm, int wn, int lane, int z, char* smem,
-                                               const float* ln_mu = nullptr, const float* ln_rs = nullptr) {
+                                               const float* ln_mu = nullptr, const float* ln_rs = nullptr,
+                                               char* gn_scratch = nullptr) {
   const int g = lane >> 4, mc = lane & 15;
   const int HoWo = p.Ho * p.Wo;
   if (p.splitk > 1) {
@@ -62,6 +74,73 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
         acc[j][i] = v;
       }
     }
+  }
+  if (p.flags & DADD_EPI_GNSTAT) {
+    // ---- GroupNorm statistics of the OUTPUT from this epilogue: the consumer's gn_stats pass — a full
+    // read of the tensor and a launch — disappears.  Host contract: full tiles, Ho*Wo % WM == 0 (a wave's rows lie in
+    // one sample), WN % cg == 0 and tile origin aligned to cg (a wave's columns hold whole groups), no split-K.
+    // Column-block outer / row-fragment inner, so only one block's partial sums are live beside the accumulators.
+    // Sums are taken over the ROUNDED fp16 values (what the consumer reads), in a fixed order: bit-reproducible.
+    float* scratch = reinterpret_cast<float*>(gn_scratch) + (wm * 2 + wn) * 256;   // [WN <= 80][2] per wave
+    const int mrow0 = m0 + wm * WM;
+    const int bsmp = mrow0 / HoWo;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int n = n0 + wn * WN + j * 16 + g * 4;
+      f4 bias4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.flags & DADD_EPI_BIAS) bias4 = *reinterpret_cast<const f4*>(p.bias + n);
+      if (p.flags & DADD_EPI_ROWVEC) bias4 += *reinterpret_cast<const f4*>(p.rowvec + (size_t)bsmp * p.ld_rowvec + n);
+      float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mrow0 + i * 16 + mc;
+        f4 v = acc[j][i] + bias4;
+        if (p.flags & DADD_EPI_RESIDUAL) {
+          const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (half_t)v[r];
+          const float f = (float)o[r];
+          cs[r] += f;
+          cq[r] = fmaf(f, f, cq[r]);
+        }
+        *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
+      }
+      // 16 lanes (mc) share a column quad: butterfly inside the DPP row (quad perms, half mirror, mirror)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cs[r] = dadd_row16_sum(cs[r]);
+        cq[r] = dadd_row16_sum(cq[r]);
+      }
+      if (mc == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          scratch[(j * 16 + g * 4 + r) * 2] = cs[r];
+          scratch[(j * 16 + g * 4 + r) * 2 + 1] = cq[r];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ngrp = WN / p.gn_cg;
+    if (lane < ngrp) {
+      float a = 0.f, q = 0.f;
+      for (int c = 0; c < p.gn_cg; ++c) {
+        a += scratch[(lane * p.gn_cg + c) * 2];
+        q += scratch[(lane * p.gn_cg + c) * 2 + 1];
+      }
+      const int chunk = (mrow0 - bsmp * HoWo) / WM;
+      const int grp = (n0 + wn * WN) / p.gn_cg + lane;
+      float* w = p.gn_ws + (((size_t)bsmp * p.gn_nchunk + chunk) * 32 + grp) * 2;
+      w[0] = a;
+      w[1] = q;
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {

@@ -328,7 +328,7 @@ int dadd_init_norm() {
 
 extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
                                   const float* gamma, const float* beta, void* out, float* ws,
-                                  int B, int HW, int groups, float eps, int silu, void* stream) {
+                                  int B, int HW, int groups, float eps, int silu, int ws_chunks, void* stream) {
   const int C = C1 + C2;
   DADD_REQUIRE(x1 && gamma && beta && out && ws, "groupnorm: null pointer");
   DADD_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0, "groupnorm: C1/C2 must be x8");
@@ -361,6 +361,15 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   p.rows_per_block = 8 * p.RP;
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ws_chunks > 0) {     // partials already written by the producer's epilogue: [B][ws_chunks][groups][2] at ws
+    DADD_REQUIRE(ws_chunks <= GN_CHUNK_MAX && C2 == 0 && groups == 32, "groupnorm: producer statistics need <= %d chunks, one source, 32 groups", GN_CHUNK_MAX);
+    p.nchunk = ws_chunks;
+    p.rows_per_chunk = (HW + ws_chunks - 1) / ws_chunks;
+    const size_t sm2p = ((size_t)2 * C + 2 * groups) * sizeof(float);
+    dadd_launch({"gn_apply_kernel<true>", 0.0, (double)B * HW * C * 4.0}, gn_apply_kernel<true>, dim3(nrb, B), dim3(256), (unsigned)sm2p, s, p);
+    DADD_LAUNCH_CHECK();
+    return DADD_OK;
+  }
   const size_t slab_bytes = (size_t)HW * p.cg * sizeof(half_t);
   const double act_bytes = (double)B * HW * C * 2.0;
   if (slab_bytes <= (size_t)GN_FUSED_MAX_BYTES && p.cg % 2 == 0 && C1 % 2 == 0) {

@@ -87,6 +87,11 @@ def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return w16, w16.double().sum(dim=1).float(), bias.float()
 
 
+# GroupNorm statistics written by the producing GEMM's epilogue (no gn_stats launch, one read of the tensor less).
+GN_FROM_EPILOGUE = True
+GN_FUSED_MAX_BYTES = 16 * 1024       # csrc/norm.hip: below this slab size the single-launch LDS GroupNorm runs
+
+
 # LayerNorm folded into the consuming linear (qkv, attn2.to_q, GEGLU projection) instead of a LayerNorm launch and a
 # normalised copy of the hidden states.  Measured in situ (profiles/r02_d_step_profile_lnfold_everywhere.txt): the row
 # statistics are 64 v_dot2c per K tile in the MFMA waves — free where those waves wait on the LDS fill (64-row tiles:
@@ -179,6 +184,7 @@ class Pool:
         self.be = be
         self.free: Dict[Tuple, List[torch.Tensor]] = {}
         self.bytes = 0
+        self.on_put = None
 
     def get(self, shape, dtype=F16) -> torch.Tensor:
         key = (tuple(shape), dtype)
@@ -192,6 +198,8 @@ class Pool:
     def put(self, *ts):
         for t in ts:
             if t is not None:
+                if self.on_put is not None:
+                    self.on_put(t)
                 self.free.setdefault((tuple(t.shape), t.dtype), []).append(t)
 
 
@@ -202,6 +210,8 @@ class _Plan:
         self.pool = Pool(be)
         self.ops: List = []
         self.keep: List[torch.Tensor] = []  # weights & persistent buffers
+        self.gn_partials: Dict[int, Tuple[torch.Tensor, int]] = {}   # output buffer -> (chunk partials, chunks)
+        self.pool.on_put = lambda t: self.gn_partials.pop(t.data_ptr(), None)   # a recycled buffer loses its statistics
         self.gn_ws = None
         # Split-K slabs are combined by the finish kernel.  The in-launch combine (last-arriving slice
         # reduces; `counters` of dadd_conv_igemm_f16) is implemented and tested but measured 2-4x SLOWER
@@ -235,7 +245,10 @@ class _Plan:
 
     # ---- recorded building blocks -----------------------------------------------------------
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
-             stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5):
+             stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5, gn_stats=False):
+        """``gn_stats``: the output feeds a GroupNorm — have the epilogue write its chunk partials (DADD_EPI_GNSTAT)
+        where the tiling allows (full 128/160-column tiles holding whole groups, row blocks inside one sample, <= 64
+        chunks, no split-K); the consuming ``gn()`` then skips its statistics pass."""
         out = self.pool.get(out_shape)
         n = w.shape[0]
         m = out_shape[0] * out_shape[1] * out_shape[2]
@@ -244,19 +257,35 @@ class _Plan:
         if ln_c1 is not None:
             sk = 1                      # the row statistics come from whole rows of A: no K slices
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
+        gkw = {}
+        if gn_stats and GN_FROM_EPILOGUE and sk == 1 and not (flags & L.EPI_GEGLU) and n % 32 == 0:
+            howo, wm_rows, cg = out_shape[1] * out_shape[2], tile_m // 2, n // 32
+            nchunk = howo // wm_rows
+            # (maps whose (batch, group) slab fits the single-launch LDS GroupNorm keep that path)
+            if (tile_n in (128, 160) and (tile_n // 2) % cg == 0 and m % tile_m == 0 and n % tile_n == 0
+                    and howo % wm_rows == 0 and 1 <= nchunk <= 64 and howo * cg * 2 > GN_FUSED_MAX_BYTES):
+                ws = self.be.zeros((out_shape[0] * nchunk * GROUPS * 2,), F32)
+                self.keep.append(ws)
+                self.gn_partials[out.data_ptr()] = (ws, nchunk)
+                gkw = dict(gn_ws=ws, gn_nchunk=nchunk)
+                flags |= L.EPI_GNSTAT
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | (L.EPI_LNFOLD if ln_c1 is not None else 0) | tune
         kw = dict(ln_c1=ln_c1, ln_eps=ln_eps) if ln_c1 is not None else {}
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
                  taps=taps, stride=stride, ups=ups, pad=pad, flags=f, splitk=sk, partial=partial,
-                 tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None, **kw)  # None: finish kernel
+                 tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None, **kw, **gkw)  # None: finish kernel
         self.pool.put(partial)
         return out
 
     def gn(self, x1, x2, gamma, beta, eps, silu):
         c = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
         out = self.pool.get((*x1.shape[:3], c))
-        self.rec(self.be.groupnorm, x1, x2, gamma, beta, out, self.gn_ws, GROUPS, eps, silu)
+        part = self.gn_partials.get(x1.data_ptr()) if x2 is None else None
+        if part is not None:            # statistics already written by the producing epilogue
+            self.rec(self.be.groupnorm, x1, None, gamma, beta, out, part[0], GROUPS, eps, silu, ws_chunks=part[1])
+        else:
+            self.rec(self.be.groupnorm, x1, x2, gamma, beta, out, self.gn_ws, GROUPS, eps, silu)
         return out
 
 
@@ -369,7 +398,7 @@ class UNetPlan(_Plan):
         off = self.temb_off[name]
         g1 = self.gn(x, skip, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1)
         h1 = self.conv(g1, self.w(name + ".conv1.weight"), (b, h, w_, cout),
-                       bias=self.f(name + ".conv1.bias"), rowvec=self.temb_rows[:, off:off + cout])
+                       bias=self.f(name + ".conv1.bias"), rowvec=self.temb_rows[:, off:off + cout], gn_stats=True)
         self.pool.put(g1)
         g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1)
         self.pool.put(h1)
@@ -380,7 +409,7 @@ class UNetPlan(_Plan):
             assert skip is None
             res = x
         out = self.conv(g2, self.w(name + ".conv2.weight"), (b, h, w_, cout),
-                        bias=self.f(name + ".conv2.bias"), residual=res)
+                        bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True)
         self.pool.put(g2)
         if res is not x:
             self.pool.put(res)
@@ -470,7 +499,7 @@ class UNetPlan(_Plan):
                        residual=h3, taps=1, pad=0)
         self.pool.put(ff, h3)
         out = self.conv(h4, self.w(site + ".proj_out.weight"), shp, bias=self.f(site + ".proj_out.bias"),
-                        residual=x, taps=1, pad=0)
+                        residual=x, taps=1, pad=0, gn_stats=True)
         self.pool.put(h4)
         return out
 

@@ -255,3 +255,34 @@ def test_module_vae_encode_protocol(full_sd):
     no_enc = _module(default_config(**{"dataset.image_size": 64}), full_sd)
     with pytest.raises(KeyError):
         no_enc.vae.encode(x)
+
+
+def test_groupnorm_statistics_from_the_producing_epilogue(monkeypatch):
+    """conv(..., gn_stats=True) -> gn(): the epilogue's chunk partials (DADD_EPI_GNSTAT) replace the statistics pass.
+    The torch backend's groupnorm NORMALISES FROM THE PARTIALS, so a wrong chunk / group layout shows up here."""
+    import torch.nn.functional as Fn
+    be = TorchRefBackend()
+    plan = E._Plan(be)
+    b, hw, cin, cout = 2, 32, 64, 320
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, hw, hw, cin, generator=g).to(torch.float16)
+    w = (torch.randn(cout, 9 * cin, generator=g) / 24).to(torch.float16)
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(b, hw, hw, cout, generator=g).to(torch.float16)
+    gamma, beta = 1 + 0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g)
+    plan.gn_ws = be.empty((b * 256 * 32 * 2,), torch.float32)
+    monkeypatch.setitem(E.TILING_OVERRIDE, E.tiling_key(b * hw * hw, cout, 9 * cin, 9, False, True), (128, 160, 1, 0))
+    out = plan.conv(x, w, (b, hw, hw, cout), bias=bias, residual=res, gn_stats=True)
+    assert out.data_ptr() in plan.gn_partials and plan.gn_partials[out.data_ptr()][1] == hw * hw // 64
+    y = plan.gn(out, None, gamma, beta, 1e-5, 1)
+    kinds = [(getattr(fn, "__name__", ""), k.get("ws_chunks", 0), bool(k.get("flags", 0) & 2048)) for fn, _, k in plan.ops]
+    assert kinds == [("igemm", 0, True), ("groupnorm", 16, False)]
+    plan.run()
+    ref = Fn.silu(Fn.group_norm(out.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    assert (y.float() - ref).abs().max().item() < 4e-3
+    plan.pool.put(out)                                   # a recycled buffer must not keep its statistics
+    assert out.data_ptr() not in plan.gn_partials
+    # split-K, 64-column tiles or a ragged tile count: no partials, the GroupNorm computes its own statistics
+    monkeypatch.setitem(E.TILING_OVERRIDE, E.tiling_key(b * hw * hw, cout, 9 * cin, 9, False, True), (128, 160, 2, 0))
+    out2 = plan.conv(x, w, (b, hw, hw, cout), bias=bias, residual=res, gn_stats=True)
+    assert out2.data_ptr() not in plan.gn_partials

@@ -593,3 +593,47 @@ def test_conditioning_small_kernels(hip):
     REF.purifier_tail(img, dis, gate, gam, bet, oref)
     hip.synchronize()
     assert (o.cpu() - oref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("case", ["halo64", "dma128x160", "dma64x160", "dma128x128", "reg64x160"])
+def test_igemm_groupnorm_statistics_epilogue(hip, case):
+    """DADD_EPI_GNSTAT on the three GEMM kernels: the chunk partials [B][Ho*Wo / (tile_m/2)][32][2] written by the
+    epilogue equal the sums of the stored fp16 outputs (fp32 accumulation order differs: 1e-3 relative), and
+    dadd_groupnorm_f16(ws_chunks=...) normalises from them exactly like the two-pass GroupNorm."""
+    from progressive_stable_diffusion_amd import lib as L
+    b = 2
+    if case == "halo64":
+        hw, cin, n, taps, tm, tn, tune = 64, 64, 320, 9, 128, 160, 0
+    elif case == "dma128x160":
+        hw, cin, n, taps, tm, tn, tune = 32, 320, 640, 1, 128, 160, 0
+    elif case == "dma64x160":
+        hw, cin, n, taps, tm, tn, tune = 32, 640, 640, 1, 64, 160, 0
+    elif case == "dma128x128":
+        hw, cin, n, taps, tm, tn, tune = 64, 128, 256, 9, 128, 128, 0
+    else:
+        hw, cin, n, taps, tm, tn, tune = 32, 320, 640, 1, 64, 160, L.TUNE_NODMA
+    x, w = rnd((b, hw, hw, cin), 90), rnd((n, taps * cin), 91, 1 / math.sqrt(taps * cin))
+    bias, rowvec, res = rnd((n,), 92, 0.1, F32), rnd((b, n), 93, 0.3, F32), rnd((b, hw, hw, n), 94)
+    nchunk = hw * hw // (tm // 2)
+    ws = hip.zeros((b * nchunk * 64,), F32)
+    o = hip.zeros((b, hw, hw, n), F16)
+    hip.igemm(dev(hip, x), dev(hip, w), o, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=taps,
+              pad=taps // 9, flags=7 | L.EPI_GNSTAT | tune, tile_m=tm, tile_n=tn, gn_ws=ws, gn_nchunk=nchunk)
+    o_ref = torch.zeros(b, hw, hw, n, dtype=F16)
+    REF.igemm(x, w, o_ref, bias=bias, rowvec=rowvec, residual=res, taps=taps, pad=taps // 9, flags=7)
+    hip.synchronize()
+    close(o, o_ref, 3e-3, 2e-3, f"gnstat out {case}")
+    oc = o.float().cpu().reshape(b, nchunk, -1, 32, n // 32)
+    part = torch.stack([oc.sum(dim=(2, 4)), (oc * oc).sum(dim=(2, 4))], dim=-1)
+    got = ws.cpu().reshape(b, nchunk, 32, 2)
+    assert (got - part).abs().max().item() <= 1e-3 * part.abs().max().item() + 1e-3, case
+    gamma, beta = rnd((n,), 95, 0.1, F32) + 1.0, rnd((n,), 96, 0.1, F32)
+    y1, y2 = hip.zeros((b, hw, hw, n), F16), hip.zeros((b, hw, hw, n), F16)
+    ws2 = hip.zeros((b * L.GN_MAX_CHUNKS * 64,), F32)
+    hip.groupnorm(o, None, dev(hip, gamma), dev(hip, beta), y1, ws, 32, 1e-5, 1, ws_chunks=nchunk)
+    hip.groupnorm(o, None, dev(hip, gamma), dev(hip, beta), y2, ws2, 32, 1e-5, 1)
+    hip.synchronize()
+    close(y1, y2.float().cpu(), 2e-3, 2e-3, f"gn from partials {case}")
+    with pytest.raises(ValueError):        # contract: no split-K with epilogue statistics
+        hip.igemm(dev(hip, x), dev(hip, w), o, taps=taps, pad=taps // 9, flags=L.EPI_GNSTAT, tile_m=tm, tile_n=tn,
+                  gn_ws=ws, gn_nchunk=nchunk, splitk=2, partial=hip.zeros((2 * b * hw * hw * n,), F32))

@@ -105,7 +105,7 @@ class TorchRefBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0):
         self.launches += 1
         xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
         b, hi, wi, cin = xin.shape
@@ -148,10 +148,24 @@ class TorchRefBackend:
         if flags & EPI_RESIDUAL:
             y = y + residual.float()
         out.copy_(y.to(out.dtype))
+        if gn_ws is not None:           # EPI_GNSTAT: chunk partials of the rounded output, [B][nchunk][32][2]
+            o = out.float().reshape(b, gn_nchunk, -1, 32, n // 32)
+            part = torch.stack([o.sum(dim=(2, 4)), (o * o).sum(dim=(2, 4))], dim=-1)
+            gn_ws[: part.numel()].copy_(part.reshape(-1))
 
-    def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu):
+    def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu, ws_chunks=0):
         x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
-        y = F.group_norm(x.permute(0, 3, 1, 2), groups, gamma.float(), beta.float(), eps)
+        if ws_chunks:                   # statistics come from the producer's partials, not from x
+            b, c = x.shape[0], x.shape[-1]
+            part = ws[: b * ws_chunks * groups * 2].reshape(b, ws_chunks, groups, 2).double().sum(dim=1)
+            cnt = x.shape[1] * x.shape[2] * (c // groups)
+            mean = part[..., 0] / cnt
+            rstd = torch.rsqrt((part[..., 1] / cnt - mean * mean).clamp_min(0) + eps)
+            xg = x.reshape(b, -1, groups, c // groups)
+            y = ((xg - mean.float()[:, None, :, None]) * rstd.float()[:, None, :, None]).reshape(x.shape)
+            y = (y * gamma.float() + beta.float()).permute(0, 3, 1, 2)
+        else:
+            y = F.group_norm(x.permute(0, 3, 1, 2), groups, gamma.float(), beta.float(), eps)
         if silu:
             y = F.silu(y)
         out.copy_(y.permute(0, 2, 3, 1).to(out.dtype))
