@@ -137,7 +137,7 @@ int dadd_mse_rows_f32(const float* pred, const float* target, float* out, int B,
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
  * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats; with ws_chunks > 0 it already
  * holds [B][ws_chunks][groups][2] partials written by the producing GEMM's epilogue (DADD_EPI_GNSTAT; x2 == NULL,
- * ws_chunks <= 64) and the statistics pass is skipped.
+ * ws_chunks <= 128) and the statistics pass is skipped.
  * Replaces nn.GroupNorm(+F.silu) in ResnetBlock2D / Transformer2DModel / VAE (+ torch.cat). */
 #define DADD_GN_MAX_CHUNKS 256
 int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,

@@ -30,7 +30,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8;
 }
 
-template <int BM, int BN, bool DEEP, bool LNF>
+template <int BM, int BN, bool DEEP>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   constexpr int WM = BM / 2;       // rows per wave (64 or 32)
   constexpr int MI = WM / 16;      // m-fragments per wave (4 or 2)
@@ -80,12 +80,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
 
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  [[maybe_unused]] float ls1[MI], ls2[MI];   // LNF: row statistics of the folded LayerNorm (igemm_args.h)
-  if constexpr (LNF) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) ls1[i] = ls2[i] = 0.f;
-  }
-
   auto gload = [&](int kt, h8 (&ra)[NA], h8 (&rb)[NB]) {
     const int kk = kt * BK;
     const int tap = kk / Cin;
@@ -139,12 +133,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
-      if constexpr (LNF) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int pr = 0; pr < 4; ++pr) ln_acc_pair(xa[i], pr, ls1[i], ls2[i]);
-      }
     }
   };
 
@@ -193,12 +181,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   }
 
   // ---- epilogue (shared with igemm_dma.hip): lane holds out[m][n .. n+3] of the swapped MFMA result
-  if constexpr (LNF) {
-    ln_finish<MI>(ls1, ls2, p.K, p.ln_eps);
-    igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, ls1, ls2);
-  } else {
-    igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + 2 * (BM + BN) * BK * 2);
-  }
+  igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + 2 * (BM + BN) * BK * 2);
 }
 
 // Finishes a split-K launch: sums the fp32 slabs and applies the (non-GEGLU) epilogue.
@@ -240,34 +223,23 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
   }
 }
 
-template <int BM, int BN, bool DEEP, bool LNF>
-int set_attr1() {
+template <int BM, int BN, bool DEEP>
+int set_attr() {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP, LNF>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
 }
-template <int BM, int BN, bool DEEP>
-int set_attr() {
-  const int rc = set_attr1<BM, BN, DEEP, false>();
-  return (rc == DADD_OK && !DEEP) ? set_attr1<BM, BN, false, true>() : rc;
-}
 
-template <int BM, int BN, bool DEEP, bool LNF>
-int launch1(const IgemmArgs& a, int nsplit, hipStream_t s) {
+template <int BM, int BN, bool DEEP>
+int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;   // + the epilogue's statistics scratch
   const int mtiles = (a.M + BM - 1) / BM;
   dim3 grid(mtiles * a.ntiles, nsplit);
-  static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " +
-                                  (DEEP ? "true" : "false") + ", " + (LNF ? "true" : "false") + ">";
-  dadd_launch({name.c_str(), dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_kernel<BM, BN, DEEP, LNF>, grid, dim3(256), smem, s, a);
+  static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + (DEEP ? "true" : "false") + ">";
+  dadd_launch({name.c_str(), dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_kernel<BM, BN, DEEP>, grid, dim3(256), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
-}
-template <int BM, int BN, bool DEEP>
-int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
-  // (with the row statistics of a folded LayerNorm the two-tiles-in-flight variant spills: one tile in flight)
-  return (a.flags & DADD_EPI_LNFOLD) ? launch1<BM, BN, false, true>(a, nsplit, s) : launch1<BM, BN, DEEP, false>(a, nsplit, s);
 }
 
 template <int BM, int BN>
@@ -393,8 +365,9 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
-  // (the 64-row LDS-DMA tiles have no upsample gather: such a request runs on the register-staged kernel)
-  const bool dma = (d->flags & DADD_TUNE_NODMA) == 0 && !(tile_m == 64 && a.ups);
+  // (the 64-row LDS-DMA tiles have no upsample gather: such a request runs on the register-staged kernel; a folded
+  // LayerNorm exists on the LDS-DMA kernel only)
+  const bool dma = ((d->flags & DADD_TUNE_NODMA) == 0 || (a.flags & DADD_EPI_LNFOLD)) && !(tile_m == 64 && a.ups);
   DADD_REQUIRE(tile_n != 64 || (dma && tile_m == 64 && !geglu), "igemm: 64-column tiles exist for the 64-row LDS-DMA kernel only");
   // persistent ring: a workgroup walks a contiguous run of tiles; with the column tile fastest the run
   // keeps ONE activation row tile (L2-hot after the first tile) and streams the weight tiles

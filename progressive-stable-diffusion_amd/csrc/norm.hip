@@ -362,7 +362,7 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (ws_chunks > 0) {     // partials already written by the producer's epilogue: [B][ws_chunks][groups][2] at ws
-    DADD_REQUIRE(ws_chunks <= GN_CHUNK_MAX && C2 == 0 && groups == 32, "groupnorm: producer statistics need <= %d chunks, one source, 32 groups", GN_CHUNK_MAX);
+    DADD_REQUIRE(ws_chunks <= 2 * GN_CHUNK_MAX && C2 == 0 && groups == 32, "groupnorm: producer statistics need <= %d chunks, one source, 32 groups", 2 * GN_CHUNK_MAX);
     p.nchunk = ws_chunks;
     p.rows_per_chunk = (HW + ws_chunks - 1) / ws_chunks;
     const size_t sm2p = ((size_t)2 * C + 2 * groups) * sizeof(float);

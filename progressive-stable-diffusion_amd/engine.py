@@ -103,7 +103,8 @@ LN_FOLD = "auto"
 
 def fold_here(m: int, n: int, k: int, geglu: bool = False) -> bool:
     if LN_FOLD == "auto":
-        return plan_tiling(m, n, k, 1, geglu, False)[0] == 64
+        tile_m, _, _, tune = plan_tiling(m, n, k, 1, geglu, False)
+        return tile_m == 64 and not (tune & L.TUNE_NODMA)       # the statistics live in the LDS-DMA kernel
     return bool(LN_FOLD)
 
 
@@ -247,7 +248,7 @@ class _Plan:
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
              stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5, gn_stats=False):
         """``gn_stats``: the output feeds a GroupNorm — have the epilogue write its chunk partials (DADD_EPI_GNSTAT)
-        where the tiling allows (full 128/160-column tiles holding whole groups, row blocks inside one sample, <= 64
+        where the tiling allows (full 128/160-column tiles holding whole groups, row blocks inside one sample, <= 128
         chunks, no split-K); the consuming ``gn()`` then skips its statistics pass."""
         out = self.pool.get(out_shape)
         n = w.shape[0]
@@ -263,7 +264,7 @@ class _Plan:
             nchunk = howo // wm_rows
             # (maps whose (batch, group) slab fits the single-launch LDS GroupNorm keep that path)
             if (tile_n in (128, 160) and (tile_n // 2) % cg == 0 and m % tile_m == 0 and n % tile_n == 0
-                    and howo % wm_rows == 0 and 1 <= nchunk <= 64 and howo * cg * 2 > GN_FUSED_MAX_BYTES):
+                    and howo % wm_rows == 0 and 1 <= nchunk <= 128 and howo * cg * 2 > GN_FUSED_MAX_BYTES):
                 ws = self.be.zeros((out_shape[0] * nchunk * GROUPS * 2,), F32)
                 self.keep.append(ws)
                 self.gn_partials[out.data_ptr()] = (ws, nchunk)

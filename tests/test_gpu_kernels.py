@@ -115,11 +115,11 @@ def test_igemm_dma_tile_shapes(hip, tile_m, tile_n, case):
 
 
 @pytest.mark.parametrize("tile_m,tile_n,tune", [(64, 64, 0), (64, 128, 0), (64, 160, 0), (128, 128, 0), (128, 160, 0),
-                                                (128, 160, 64), (64, 160, 32), (128, 128, 32), (64, 128, 48)])
+                                                (128, 160, 64), (64, 160, 32)])
 @pytest.mark.parametrize("geglu", [False, True])
 def test_igemm_layernorm_fold(hip, tile_m, tile_n, tune, geglu):
     """DADD_EPI_LNFOLD on every kernel that can carry it (LDS-DMA tiles, persistent ring = tune 64, register-staged
-    = tune 32 / 48): out = rstd (x (gamma o W)^T - mu c1) + (W beta + b) with mu / rstd accumulated from the A
+    = tune 32: served by the LDS-DMA kernel, the only one with the statistics): out = rstd (x (gamma o W)^T - mu c1) + (W beta + b) with mu / rstd accumulated from the A
     fragments, against LayerNorm -> Linear in fp32 torch.  Rows with a large common offset (|mean| = 3 sigma)
     exercise the cancellation of the mean term.  Tolerance: one fp16 rounding of the result + fp16 weights."""
     from progressive_stable_diffusion_amd import engine as E
@@ -127,7 +127,7 @@ def test_igemm_layernorm_fold(hip, tile_m, tile_n, tune, geglu):
     import torch.nn.functional as Fn
     if geglu and tile_n != 128:
         pytest.skip("the GEGLU epilogue runs on 128-column tiles")
-    m, k = (1200 if tune != 64 else 40000), 640
+    m, k = (20000 if tune != 64 else 40000), 640
     n = 1024 if tile_n != 160 else 960
     if geglu:
         n = 1024
@@ -150,6 +150,13 @@ def test_igemm_layernorm_fold(hip, tile_m, tile_n, tune, geglu):
               ln_c1=dev(hip, c1.contiguous()))
     hip.synchronize()
     close(o, ref, 6e-3, 6e-3, f"ln fold {tile_m}x{tile_n} tune{tune} geglu{geglu}")
+    o2 = hip.zeros(tuple(o.shape), F16)                  # run to run: bit-identical (no race in the statistics)
+    for _ in range(3):
+        hip.igemm(dev(hip, x), dev(hip, w16.contiguous()), o2, bias=dev(hip, bias.contiguous()),
+                  flags=L.EPI_BIAS | L.EPI_LNFOLD | (L.EPI_GEGLU if geglu else 0) | tune, tile_m=tile_m, tile_n=tile_n,
+                  ln_c1=dev(hip, c1.contiguous()))
+        hip.synchronize()
+        assert torch.equal(o2, o)
     if not geglu:
         with pytest.raises(ValueError):       # a folded LayerNorm needs whole rows of A: no split-K
             hip.igemm(dev(hip, x), dev(hip, w16.contiguous()), o, flags=L.EPI_LNFOLD, splitk=2,
