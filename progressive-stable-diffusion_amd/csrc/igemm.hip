@@ -369,9 +369,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // LayerNorm exists on the LDS-DMA kernel only)
   const bool dma = ((d->flags & DADD_TUNE_NODMA) == 0 || (a.flags & DADD_EPI_LNFOLD)) && !(tile_m == 64 && a.ups);
   DADD_REQUIRE(tile_n != 64 || (dma && tile_m == 64 && !geglu), "igemm: 64-column tiles exist for the 64-row LDS-DMA kernel only");
-  // persistent ring: a workgroup walks a contiguous run of tiles; with the column tile fastest the run
-  // keeps ONE activation row tile (L2-hot after the first tile) and streams the weight tiles
-  if (dma && tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit)) a.gm = a.gn = 0;
+  // persistent ring: a workgroup walks a contiguous run of tiles.  Activation-heavy GEMMs: column tile fastest, the
+  // run keeps ONE activation row tile (L2-hot after the first tile) and streams the (L2-resident) weight tiles.
+  // Weight-heavy GEMMs (the GEGLU projection of the 16x16 map: 26 MB of weights against 2.6 MB of activations) keep
+  // the grouped order: row tile fastest inside a group of column tiles, so the runs of neighbouring workgroups —
+  // same XCD, started together — read each weight tile from HBM once instead of once per row tile.
+  if (dma && tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit) &&
+      ((d->flags & DADD_TUNE_SHALLOW) ? false : 2.0 * a.B * a.Hi * a.Wi * Cin >= 2.0 * a.N * a.K))
+    a.gm = a.gn = 0;
   // 3x3 / stride 1 on whole-row tiles: the halo-resident kernel (conv_halo.hip); K slices = channel chunks
   const bool halo = dma && tile_m == 128 && dadd_conv_halo_applicable(a, tile_n);
   int halo_ns = 1;

@@ -34,6 +34,7 @@ def candidates(key, N_CU=256):
             out.append((128, tn, sk, 0))
         if t128 > N_CU and not ups:
             out.append((128, tn, 1, L.TUNE_PERSIST))
+            out.append((128, tn, 1, L.TUNE_PERSIST | L.TUNE_SHALLOW))   # persistent ring, grouped (row-fastest) tile order
         if not ups:
             out.append((64, tn, 1, 0))                      # 64-row LDS-DMA tiles
             out.append((64, tn, 1, L.TUNE_NODMA))           # 64-row register-staged tiles (two workgroups per CU)
