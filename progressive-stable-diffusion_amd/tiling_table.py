@@ -15,5 +15,11 @@ TABLE = {
     (4096, 640, 1920, 1, False, False, 0, 1): (64, 160, 1, 0),
     (4096, 640, 2560, 1, False, True, 0, 1): (64, 160, 1, 0),
     (16384, 320, 960, 1, False, False, 0, 1): (128, 160, 1, 0),
+    # second sweep (gpurun_out/r02i -> profiles/r02_i_tile_sweep.txt)
+    (1024, 3840, 1280, 1, False, False, 0, 1): (128, 160, 1, 0),
+    (4096, 1920, 640, 1, False, False, 0, 1): (128, 160, 1, 32),
+    (16384, 320, 320, 1, False, False, 0, 1): (64, 160, 1, 32),
+    (16384, 320, 640, 1, False, False, 0, 1): (128, 160, 1, 0),
+    (16384, 320, 1280, 1, False, True, 0, 1): (128, 160, 1, 0),
     (16384, 2560, 320, 1, True, False, 0, 1): (128, 128, 1, 32),
 }

@@ -2,7 +2,7 @@
 # HBM traffic of the dominant kernel, per MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE in SEPARATE
 # rocprofv3 --pmc passes (no trace domains), KB units, FETCH_SIZE doubled on gfx950.
 set -u
-tag=${1:-traffic}; out=gpurun_out/$tag; mkdir -p "$out"; export TMPDIR=/tmp
+tag=${1:-traffic}; export DOM="${2:-igemm_dma_kernel<128, 160, false, false, false>}"; out=gpurun_out/$tag; mkdir -p "$out"; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d "$out/$c" -- python scripts/step_pmc.py > "$out/$c.log" 2>&1
@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   if [ $rc -ne 0 ]; then exit $rc; fi
 done
 python3 - "$out" <<'PY'
-import csv, glob, json, sys, collections, re
+import csv, glob, json, os, sys, collections, re
 out = sys.argv[1]
 res = {}
 def kname(s):
@@ -26,7 +26,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         k = kname(r["Kernel_Name"])
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     res[c] = {k: {"sum_kb": v[0], "dispatches": v[1], "avg_kb": v[0] / v[1]} for k, v in agg.items()}
-dom = [k for k in res["FETCH_SIZE"] if "igemm_dma_kernel<160, false, false, true>" in k]
+dom = [k for k in res["FETCH_SIZE"] if os.environ["DOM"].replace(" ", "") in k.replace(" ", "")]
 summary = {"counters": res}
 if dom:
     k = dom[0]

@@ -14,7 +14,7 @@ from progressive_stable_diffusion_amd.config import default_config  # noqa: E402
 from progressive_stable_diffusion_amd.diffusion_module_ip import DiffusionModuleWithIP  # noqa: E402
 
 dev = torch.device("cuda:0")
-tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1,
             image_size=224, patch_size=14, projection_dim=32)
 shapes = dict(W.unet_shapes())
 shapes.update(W.conditioning_shapes(clip_hidden=64))
