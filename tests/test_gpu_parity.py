@@ -673,3 +673,24 @@ def test_training_step_forward_on_device(full_sd):
                           rtol=1e-6, atol=1e-6)          # fp32; the device square roots may differ in the last place
     l2 = mod.training_step((images.to(DEV), labels.to(DEV), pix.to(DEV)))            # device RNG everywhere: finite
     assert torch.isfinite(l2) and l2.item() > 0.0
+
+
+def test_config5_geometry_768_properties(full_sd):
+    """BASELINE config 5's GEOMETRY (768x768, B = 2: 96x96 / 48x48 / 24x24 / 12x12 maps, 9216-token self-attention)
+    through the fp16 kernels: finite, clamped, deterministic, steering acts, frames in range.  The fp8-e4m3 attention
+    and bf16 convolutions config 5 names are NOT built; 96-pixel rows run on the implicit GEMM (the halo
+    conv covers 16 / 32 / 64-pixel rows)."""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 768, 2)
+    pix = (torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    lat = torch.randn(1, 4, 96, 96, generator=torch.Generator().manual_seed(5)).repeat(2, 1, 1, 1)
+    tgt, src = torch.tensor([3.0, 2.0], device=DEV), torch.full((2,), 2.0, device=DEV)
+    with torch.no_grad():
+        z = PIPE._ddim_sample_ip(mod, tgt, src, pix, 6, DEV, steer_scale=3.0, latents=lat)
+        z2 = PIPE._ddim_sample_ip(mod, tgt, src, pix, 6, DEV, steer_scale=3.0, latents=lat)
+        z0 = PIPE._ddim_sample_ip(mod, tgt, src, pix, 6, DEV, steer_scale=0.0, latents=lat)
+        img = PIPE._latents_to_images(mod, z)
+    assert z.shape == (2, 4, 96, 96) and torch.isfinite(z).all() and float(z.abs().max()) <= 4.0 + 1e-6
+    assert torch.equal(z, z2)
+    assert (z[1] - z0[1]).abs().max().item() < 1e-5 and (z[0] - z0[0]).abs().max().item() > 1e-3
+    assert img.shape == (2, 3, 768, 768) and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
