@@ -6,7 +6,6 @@
 namespace {
 
 constexpr int GN_MAXV = 2;  // 16-byte channel vectors per thread: C <= 8*256*2 = 4096
-constexpr int GN_INFLIGHT = 8;   // rows (16-byte loads per channel vector) in flight per thread
 
 struct GnArgs {
   const half_t* x1;
@@ -39,13 +38,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
     for (int e = 0; e < 8; ++e) s[u][e] = ss[u][e] = 0.f;
   const int nvec = p.C >> 3;
   if (tr < p.RP) {
-    // GN_INFLIGHT rows per trip, all loads issued before the first use.  Little's law sets the number: ~2 us of
-    // fabric latency x ~5 TB/s = ~10 MB must be in flight on the chip; with one 16-B load per thread the pass was
-    // latency-bound (9.5 us for 10.5 MB), with four it ran at 1.0-1.8 TB/s.
-    for (int row = row0 + tr; row < row1; row += GN_INFLIGHT * p.RP) {
-      h8 xv[GN_INFLIGHT][GN_MAXV];
+    // four rows per trip, all loads issued before the first use: one 16-B load in flight per thread
+    // made this pass latency-bound (9.5 us for 10.5 MB)
+    for (int row = row0 + tr; row < row1; row += 4 * p.RP) {
+      h8 xv[4][GN_MAXV];
 #pragma unroll
-      for (int q = 0; q < GN_INFLIGHT; ++q) {
+      for (int q = 0; q < 4; ++q) {
         const int rr = row + q * p.RP;
         const size_t pix = (size_t)b * p.HW + (rr < row1 ? rr : row);
 #pragma unroll
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
         }
       }
 #pragma unroll
-      for (int q = 0; q < GN_INFLIGHT; ++q) {
+      for (int q = 0; q < 4; ++q) {
         if (row + q * p.RP >= row1) continue;
 #pragma unroll
         for (int u = 0; u < GN_MAXV; ++u) {
@@ -175,10 +173,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
       sh[u][e] = v < nvec ? shift[v * 8 + e] : 0.f;
     }
   }
-  for (int row = row0 + tr; row < row1; row += GN_INFLIGHT * p.RP) {   // GN_INFLIGHT rows in flight per thread
-    h8 xv[GN_INFLIGHT][GN_MAXV];
+  for (int row = row0 + tr; row < row1; row += 4 * p.RP) {   // four rows in flight per thread
+    h8 xv[4][GN_MAXV];
 #pragma unroll
-    for (int q = 0; q < GN_INFLIGHT; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const int rr = row + q * p.RP;
       const size_t pix = (size_t)b * p.HW + (rr < row1 ? rr : row);
 #pragma unroll
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p) {
         if (tv + u * p.TV < nvec) xv[q][u] = gn_load(p, pix, (tv + u * p.TV) * 8);
     }
 #pragma unroll
-    for (int q = 0; q < GN_INFLIGHT; ++q) {
+    for (int q = 0; q < 4; ++q) {
       const int rr = row + q * p.RP;
       if (rr >= row1) continue;
       const size_t pix = (size_t)b * p.HW + rr;
@@ -264,67 +262,58 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnArgs p) {
 constexpr int GN_CHUNK_MAX = 64;
 constexpr int GN_FUSED_MAX_BYTES = 16 * 1024;   // measured: wins only below ~16 KiB per (batch, group) slab
 
-// LayerNorm: one wave per LN_ROWS rows, the rows live in registers (exact two-pass variance).  Two rows per wave keep
-// twice the bytes in flight (the kernel ran at 1.8 TB/s with one: latency-bound, not bandwidth-bound).
+// LayerNorm: one wave per row, the row lives in registers (exact two-pass variance).
 constexpr int LN_MAXV = 4;  // C <= 8*64*4 = 2048
-constexpr int LN_ROWS = 2;
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         half_t* __restrict__ out, int M, int C,
                                                         float eps) {
   const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
-  if (row0 >= M) return;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
   const int nvec = C >> 3;
-  h8 v[LN_ROWS][LN_MAXV];
+  const half_t* xr = x + (size_t)row * C;
+  h8 v[LN_MAXV];
+  float sum = 0.f;
 #pragma unroll
-  for (int r = 0; r < LN_ROWS; ++r) {
-    const int row = min(row0 + r, M - 1);
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+      v[u] = *reinterpret_cast<const h8*>(xr + i * 8);
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
-      const int i = lane + 64 * u;
-      if (i < nvec) v[r][u] = *reinterpret_cast<const h8*>(x + (size_t)row * C + i * 8);
+      for (int e = 0; e < 8; ++e) sum += (float)v[u][e];
     }
   }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
 #pragma unroll
-  for (int r = 0; r < LN_ROWS; ++r) {
-    if (row0 + r >= M) break;
-    float sum = 0.f;
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u)
-      if (lane + 64 * u < nvec) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += (float)v[r][u][e];
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[u][e] - mean;
+        sq += d * d;
       }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u)
-      if (lane + 64 * u < nvec) {
+  for (int u = 0; u < LN_MAXV; ++u) {
+    const int i = lane + 64 * u;
+    if (i < nvec) {
+      h8 o;
+      const f4 g0 = *reinterpret_cast<const f4*>(gamma + i * 8);
+      const f4 g1 = *reinterpret_cast<const f4*>(gamma + i * 8 + 4);
+      const f4 b0 = *reinterpret_cast<const f4*>(beta + i * 8);
+      const f4 b1 = *reinterpret_cast<const f4*>(beta + i * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = (float)v[r][u][e] - mean;
-          sq += d * d;
-        }
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)(((float)v[u][e] - mean) * rstd * g0[e] + b0[e]);
+        o[e + 4] = (half_t)(((float)v[u][e + 4] - mean) * rstd * g1[e] + b1[e]);
       }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-#pragma unroll
-    for (int u = 0; u < LN_MAXV; ++u) {
-      const int i = lane + 64 * u;
-      if (i < nvec) {
-        h8 o;
-        const f4 g0 = *reinterpret_cast<const f4*>(gamma + i * 8);
-        const f4 g1 = *reinterpret_cast<const f4*>(gamma + i * 8 + 4);
-        const f4 b0 = *reinterpret_cast<const f4*>(beta + i * 8);
-        const f4 b1 = *reinterpret_cast<const f4*>(beta + i * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (half_t)(((float)v[r][u][e] - mean) * rstd * g0[e] + b0[e]);
-          o[e + 4] = (half_t)(((float)v[r][u][e + 4] - mean) * rstd * g1[e] + b1[e]);
-        }
-        *reinterpret_cast<h8*>(out + (size_t)(row0 + r) * C + i * 8) = o;
-      }
+      *reinterpret_cast<h8*>(out + (size_t)row * C + i * 8) = o;
     }
   }
 }
@@ -404,7 +393,7 @@ extern "C" int dadd_layernorm_f16(const void* x, const float* gamma, const float
                "layernorm: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXV);
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(out) && dadd_aligned16(gamma) &&
                    dadd_aligned16(beta), "layernorm: pointers must be 16-byte aligned");
-  dadd_launch({"layernorm_kernel", 0.0, (double)M * C * 4.0}, layernorm_kernel, dim3((M + 4 * LN_ROWS - 1) / (4 * LN_ROWS)), dim3(256), 0,
+  dadd_launch({"layernorm_kernel", 0.0, (double)M * C * 4.0}, layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0,
               static_cast<hipStream_t>(stream), static_cast<const half_t*>(x), gamma, beta,
               static_cast<half_t*>(out), M, C, eps);
   DADD_LAUNCH_CHECK();
