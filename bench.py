@@ -126,13 +126,11 @@ def live_roofline(mod, a, side, lat, dev, n_steps=2):
     events) with every launch's own begin/end timestamps recorded (hipExtLaunchKernelGGL event pair = the clock of
     rocprofv3's kernel trace, so ``avg_launch_us`` is directly comparable with the AverageNs column of the
     committed profiles/*_kernel_stats.csv).  achieved = sum of algorithmic flop (2*M*N*K) or bytes over the
-    launches of that kernel / sum of their durations.  With sampler lanes the table is that of ONE lane's step (its half
-    batch), replayed alone."""
-    lanes = mod.ddim_lanes(a.batch, side)      # the timed passes ran these plans (half batches on two streams)
-    loop, lo, hi = lanes[0]
+    launches of that kernel / sum of their durations."""
+    loop = mod.ddim_loop(a.batch, side)
     be = loop.be
     with torch.no_grad():    # same state as the timed passes: cond projected, tables prepared
-        be.copy_(loop.u.lat_in, lat[lo:hi].to(dev))
+        be.copy_(loop.u.lat_in, lat.to(dev))
         be.zero_(loop.step)
         loop._one_step(a.steer_scale, False, 1.0)      # warm: the eager path's first launch of each kernel
         be.synchronize()
@@ -164,7 +162,6 @@ def live_roofline(mod, a, side, lat, dev, n_steps=2):
             "algorithmic_per_launch": (dom["flop"] if mfma else dom["bytes"]) / dom["calls"],
             "timing": "per-launch begin/end timestamps of the dispatch (hipExtLaunchKernelGGL events) over an eager "
                       f"replay of {n_steps} steps right after the timed region; same clock as rocprofv3 --kernel-trace",
-            "sampler_lanes": len(lanes), "lane_batch": hi - lo,
             "step_kernel_us": total_us / n_steps, "step_launches": len(rec) / n_steps,
             "all_mfma_kernels_tflops": sum(t["flop"] for t in gemm) / (sum(t["us"] for t in gemm) * 1e-6) / 1e12,
             "top_kernels": [{"name": t["name"], "share": round(t["share"], 4), "calls_per_step": t["calls_per_step"],

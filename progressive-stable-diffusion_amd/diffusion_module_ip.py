@@ -353,22 +353,18 @@ class DiffusionModuleWithIP:
         self.image_projection = proj_cls(state_dict, self.device, dc.num_image_tokens, be=self.be)
         self.feature_purifier = (FeaturePurifier(state_dict, self.device, dc.purifier_num_heads, be=self.be)
                                  if dc.use_feature_purifier else None)
-        self._unets: Dict[Tuple, OrdinalUNet] = {}
-        self._loops: Dict[Tuple, DdimLoop] = {}
-        self._wcache: Dict = {}                 # packed UNet weights, shared by the plans of every batch size / lane
-        self._lane_backends = [self.be]         # sampler lanes: independent HIP streams over the same weights
-        self._own_backend = backend is None
+        self._unets: Dict[Tuple[int, int], OrdinalUNet] = {}
+        self._loops: Dict[Tuple[int, int], DdimLoop] = {}
         self.unet = self._unet_for(self.batch_size, self.latent_side)
         self.vae = SDVAE(self.be, state_dict, self.batch_size, self.latent_side, dc.latent_scale)
 
     # ---- plans per (batch, side) ----------------------------------------------------------------
-    def _unet_for(self, batch: int, side: int, lane: int = 0) -> OrdinalUNet:
-        key = (batch, side) if lane == 0 else (batch, side, lane)
-        u = self._unets.get(key)
+    def _unet_for(self, batch: int, side: int) -> OrdinalUNet:
+        u = self._unets.get((batch, side))
         if u is None:
             dc = self.diff_cfg
-            plan = UNetPlan(self._lane_backend(lane), self._sd, batch, side, use_routing_gates=dc.use_routing_gates,
-                            use_frequency_strategy=dc.use_frequency_strategy, wcache=self._wcache)
+            plan = UNetPlan(self.be, self._sd, batch, side, use_routing_gates=dc.use_routing_gates,
+                            use_frequency_strategy=dc.use_frequency_strategy)
             u = OrdinalUNet(plan, dc.use_routing_gates, self.cfg.model.conditioning_dim,
                             self.cfg.model.latent_channels, self.cfg.model.latent_channels)
             if self._unets:     # keep delta_scale consistent across plans
@@ -376,39 +372,15 @@ class DiffusionModuleWithIP:
                 for _, s in u.unet.named_modules():
                     if hasattr(s.processor, "delta_scale"):
                         s.processor.delta_scale = lam
-            self._unets[key] = u
+            self._unets[(batch, side)] = u
         return u
 
-    def _lane_backend(self, lane: int):
-        """Backend (= HIP stream) of sampler lane ``lane``; lane 0 is the module's own."""
-        while len(self._lane_backends) <= lane:
-            if self._own_backend:
-                from .backend import HipBackend
-                self._lane_backends.append(HipBackend(self.device))
-            else:                               # injected backend (CPU wiring tests): lanes share it, no concurrency
-                self._lane_backends.append(self.be)
-        return self._lane_backends[lane]
-
-    def ddim_loop(self, batch: int, side: int, lane: int = 0) -> DdimLoop:
-        key = (batch, side) if lane == 0 else (batch, side, lane)
-        lp = self._loops.get(key)
+    def ddim_loop(self, batch: int, side: int) -> DdimLoop:
+        lp = self._loops.get((batch, side))
         if lp is None:
-            lp = DdimLoop(self._unet_for(batch, side, lane)._plan)
-            self._loops[key] = lp
+            lp = DdimLoop(self._unet_for(batch, side)._plan)
+            self._loops[(batch, side)] = lp
         return lp
-
-    # Sampler lanes.  A denoising step is ~400 dependent launches; every launch sits on a ~4 us floor (wave launch, first
-    # load from the fabric, end-of-kernel write-back) plus ~1.5 us to the next one, and many of them do not fill 256 CUs.
-    # Two HALF-batch chains on two HIP streams — same weights, own plans and step graphs — let one chain's kernels run
-    # under the other's launch floors and tails.  Samples are independent, so nothing is exchanged between lanes.
-    sampler_lanes = 2
-
-    def ddim_lanes(self, batch: int, side: int):
-        """[(loop, lo, hi)]: the sample ranges of a batch and the loop (own stream) that denoises each."""
-        n = self.sampler_lanes if (self.sampler_lanes > 1 and batch >= 2 * self.sampler_lanes
-                                   and batch % self.sampler_lanes == 0) else 1
-        per = batch // n
-        return [(self.ddim_loop(per, side, lane), lane * per, (lane + 1) * per) for lane in range(n)]
 
     # ---- reference protocol -----------------------------------------------------------------------
     @classmethod

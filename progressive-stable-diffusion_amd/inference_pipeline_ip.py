@@ -188,25 +188,19 @@ def _ddim_sample_ip(module: DiffusionModuleWithIP, target_labels: Tensor, source
         return _ddim_stochastic(module, latents, timesteps, embed_cond, embed_uncond, guidance_scale, eta,
                                 step_noise=step_noise)
 
-    # one loop per sampler lane (half batches on independent streams, diffusion_module_ip.ddim_lanes); per-step traces
-    # and eager runs stay on one lane
-    lanes = module.ddim_lanes(num_samples, side) if (use_graph and trace is None) else [(module.ddim_loop(num_samples, side), 0, num_samples)]
-    lam = float(steer_scale) if use_routing_gates else 0.0
-    for loop, lo, hi in lanes:
-        plan, be = loop.u, loop.be
-        be.wait_current()
-        plan.set_cond(embed_cond[lo:hi], 0)
-        if do_cfg:
-            plan.set_cond(embed_uncond[lo:hi], 1)
-        loop.prepare(timesteps, module.alphas_cumprod)
-        be.copy_(plan.lat_in, latents[lo:hi])
-    for loop, lo, hi in lanes:                    # enqueue: the lanes' step graphs run concurrently on the device
-        loop.run(lam, do_cfg, float(guidance_scale), use_graph=use_graph, trace=trace)
-    outs = []
-    for loop, lo, hi in lanes:
-        outs.append(loop.be.clone(loop.u.lat_in))
-        loop.be.release_to_current()
-    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+    loop = module.ddim_loop(num_samples, side)
+    plan, be = loop.u, loop.be
+    be.wait_current()
+    plan.set_cond(embed_cond, 0)
+    if do_cfg:
+        plan.set_cond(embed_uncond, 1)
+    loop.prepare(timesteps, module.alphas_cumprod)
+    be.copy_(plan.lat_in, latents)
+    loop.run(float(steer_scale) if use_routing_gates else 0.0, do_cfg, float(guidance_scale),
+             use_graph=use_graph, trace=trace)
+    out = be.clone(plan.lat_in)
+    be.release_to_current()
+    return out
 
 
 def _ddim_sample_batched(module: DiffusionModuleWithIP, target_labels: Tensor, source_labels: Tensor,
