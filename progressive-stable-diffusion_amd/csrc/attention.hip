@@ -81,8 +81,10 @@ __device__ __forceinline__ int kpanel_off(int row, int chunk) {
 // per score), the mask runs only on a ragged last tile, O is rescaled only when a row maximum moved,
 // probabilities are converted pairwise, and — when the head dim leaves a spare column in its
 // 16-multiple (d = 40 -> 48) — a column of ones in V makes the PV MFMA produce the softmax row sums.
+// (two blocks per CU for the small head dims: 256 VGPRs per lane at most — at 260 the d = 40 kernel ran one block per
+// CU and took 242 instead of 172 us)
 template <int DR, int QF, bool PREFETCH>
-__global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
+__global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const FlashArgs p) {
   constexpr bool DEEP = PREFETCH && DR <= 40;   // two tiles in flight where the registers allow it
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int KS = D / 32, DF = DVP / 16, DC = DR / 8;
@@ -138,13 +140,14 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   }
 
   // hoisted tile addressing: what this thread loads / stores for every tile
-  int g_off[NL], k_lds[NL], v_lds[NL], t_row[NL];
+  int g_off[NL], g_off_c[NL], k_lds[NL], v_lds[NL], t_row[NL];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
     const int idx = t + 256 * u;
     const int row = idx / DC, ch = idx - row * DC;
     t_row[u] = (idx < 64 * DC) ? row : 1 << 30;      // rows past the tile never pass the key test
     g_off[u] = row * p.ld + h * DR + ch * 8;
+    g_off_c[u] = min(row, 63) * p.ld + h * DR + ch * 8;   // in-tile address for every thread (full tiles)
     k_lds[u] = (ch >> 3) * 4096 + kpanel_off(row, ch & 7);
     v_lds[u] = row * VLD + ch * 8;
   }
@@ -174,11 +177,19 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   auto tile_load = [&](int kt, h8 (&rk)[PREFETCH ? NL : 1], h8 (&rv)[PREFETCH ? NL : 1]) {
     const size_t toff = (size_t)kt * 64 * p.ld;
     const int kmax = p.N - kt * 64;                  // rows < kmax are real keys
+    if (kmax >= 64) {                                // full tile (wave-uniform): no per-register selects — the address
+#pragma unroll                                       // of a thread without a row is clamped, its store is skipped
+      for (int u = 0; u < (PREFETCH ? NL : 1); ++u) {
+        rk[u] = *reinterpret_cast<const h8*>(kbase + toff + g_off_c[u]);
+        rv[u] = *reinterpret_cast<const h8*>(vbase + toff + g_off_c[u]);
+      }
+    } else {
 #pragma unroll
-    for (int u = 0; u < (PREFETCH ? NL : 1); ++u) {
-      const bool ok = t_row[u] < kmax;
-      rk[u] = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
-      rv[u] = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
+      for (int u = 0; u < (PREFETCH ? NL : 1); ++u) {
+        const bool ok = t_row[u] < kmax;
+        rk[u] = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
+        rv[u] = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
+      }
     }
   };
   auto tile_store = [&](int buf, const h8 (&rk)[PREFETCH ? NL : 1], const h8 (&rv)[PREFETCH ? NL : 1]) {
@@ -197,12 +208,11 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
   auto compute = [&](int kt, int buf) {
     const half_t* Kc = Ks + buf * TILE_HALFS;
     const half_t* Vc = Vs + buf * TILE_HALFS;
-    // ---- S^T = K Q^T : sacc[kf][f], rows = keys kf*16 + 4g + r, column = query li
+    // ---- S^T = K Q^T : sacc[kf][f], rows = keys kf*16 + 4g + r, column = query li.  The first K step takes a literal
+    // zero as its C operand (an inline constant of the MFMA): no per-tile zeroing of the 16 * QF score registers — this
+    // kernel is bound by VALU issue, and those moves were 64 of its ~560 vector instructions per tile.
     f4 sacc[4][QF];
-#pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-      for (int f = 0; f < QF; ++f) sacc[kf][f] = f4{0.f, 0.f, 0.f, 0.f};
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const half_t* kp = Kc + (s >> 1) * 4096 + ka_off[s & 1];
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
         const h8 ka = *reinterpret_cast<const h8*>(kp + kf * 1024);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
-          sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], sacc[kf][f], 0, 0, 0);
+          sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], s == 0 ? zero4 : sacc[kf][f], 0, 0, 0);
       }
     }
 
@@ -229,10 +239,14 @@ __global__ __launch_bounds__(256) void flash_kernel(const FlashArgs p) {
     }
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      float mx = fmaxf(fmaxf(sacc[0][f][0], sacc[0][f][1]), fmaxf(sacc[0][f][2], sacc[0][f][3]));
+      // 16 scores -> one maximum in 8 three-input maxima (v_max3_f32), a linear chain the compiler keeps as such
+      float mx = fmaxf(sacc[0][f][0], sacc[0][f][1]);
+      mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[0][f][2]), sacc[0][f][3]);
 #pragma unroll
-      for (int kf = 1; kf < 4; ++kf)
-        mx = fmaxf(fmaxf(fmaxf(mx, sacc[kf][f][0]), sacc[kf][f][1]), fmaxf(sacc[kf][f][2], sacc[kf][f][3]));
+      for (int kf = 1; kf < 4; ++kf) {
+        mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[kf][f][0]), sacc[kf][f][1]);
+        mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[kf][f][2]), sacc[kf][f][3]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrow[f], mx * p.scale_log2);      // running max in log2 units
