@@ -27,9 +27,9 @@ for s in $steps; do
     stepprofvae) TAILN=40 run stepprofvae 600 python scripts/step_profile.py --vae --list --out "$out/step_profile_vae.txt" ;;
     opbench) TAILN=80 run opbench 600 python scripts/op_bench.py "$tag" ;;
     opbenchvae) TAILN=60 run opbenchvae 600 python scripts/op_bench.py "$tag" --vae ;;
-    bench)   run bench 900 python bench.py --steps 2 --warmup 1 ;;
+    bench)   run bench 900 python bench.py --steps 3 --warmup 1 ;;
     prof)    export TMPDIR=/tmp
-             run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline
+             run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
              find "$out/prof" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} sh -c 'head -40 "{}" > '"$out"'/kernel_stats_top.csv'
              find "$out/prof" -name "*kernel_trace*.csv" -size +20M -delete 2>/dev/null ;;
     pmc)     export TMPDIR=/tmp
