@@ -223,6 +223,66 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
   }
 }
 
+// Finish of a split-K launch whose output feeds a GroupNorm (DADD_EPI_GNSTAT): same sums and epilogue as above, but a
+// block owns 64 rows x CB columns (whole groups) and also writes their (sum, sum of squares) per group into the
+// GroupNorm's chunk partials [B][Ho*Wo/64][32][2] — the consumer then needs no statistics pass.  Fixed summation order.
+template <int CB>
+__global__ __launch_bounds__(256) void splitk_finish_gn_kernel(const IgemmArgs p, int nsplit) {
+  constexpr int Q = CB / 4, RL = 256 / Q;          // channel quads per row, row lanes (40 x 6 or 32 x 8)
+  __shared__ float red[RL][CB][2];
+  const int t = threadIdx.x, q = t % Q, rl = t / Q;
+  const int n = blockIdx.y * CB + q * 4;
+  const int m_base = blockIdx.x * 64;
+  const int HoWo = p.Ho * p.Wo;
+  const int bsmp = m_base / HoWo;
+  const size_t sstride = (size_t)p.M * p.N;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    f4 add = {0.f, 0.f, 0.f, 0.f};
+    if (p.flags & DADD_EPI_BIAS) add = *reinterpret_cast<const f4*>(p.bias + n);
+    if (p.flags & DADD_EPI_ROWVEC) add += *reinterpret_cast<const f4*>(p.rowvec + (size_t)bsmp * p.ld_rowvec + n);
+    for (int r = rl; r < 64; r += RL) {
+      const int m = m_base + r;
+      const float* slab = p.partial + (size_t)m * p.N + n;
+      f4 v = add;
+      for (int s2 = 0; s2 < nsplit; ++s2) v += *reinterpret_cast<const f4*>(slab + (size_t)s2 * sstride);
+      if (p.flags & DADD_EPI_RESIDUAL) {
+        const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+      }
+      h4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)v[e];
+        const float f = (float)o[e];
+        cs[e] += f;
+        cq[e] = fmaf(f, f, cq[e]);
+      }
+      *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[rl][q * 4 + e][0] = cs[e];
+      red[rl][q * 4 + e][1] = cq[e];
+    }
+  }
+  __syncthreads();
+  const int ngrp = CB / p.gn_cg;
+  if (t < ngrp) {
+    float a = 0.f, qq = 0.f;
+    for (int c = 0; c < p.gn_cg; ++c)
+      for (int r = 0; r < RL; ++r) {
+        a += red[r][t * p.gn_cg + c][0];
+        qq += red[r][t * p.gn_cg + c][1];
+      }
+    const int chunk = (m_base - bsmp * HoWo) / 64;
+    float* w = p.gn_ws + (((size_t)bsmp * p.gn_nchunk + chunk) * 32 + (blockIdx.y * CB) / p.gn_cg + t) * 2;
+    w[0] = a;
+    w[1] = qq;
+  }
+}
+
 template <int BM, int BN, bool DEEP>
 int set_attr() {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;
@@ -354,14 +414,6 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // consecutive K tiles — measured no different: the DMA stream is bound by the L2->LDS fill rate of a CU, not by
   // L1 hits: profiles/r01_x_dma_limits.txt.)
   a.korder = 0;
-  if (a.flags & DADD_EPI_GNSTAT) {
-    const int wm_rows = tile_m / 2, wn_cols = tile_n / 2, howo = a.Ho * a.Wo;
-    DADD_REQUIRE(a.gn_ws && a.gn_cg > 0 && a.N == 32 * a.gn_cg && !geglu && nsplit == 1 && (tile_n == 128 || tile_n == 160) &&
-                     wn_cols % a.gn_cg == 0 && a.M % tile_m == 0 && a.N % tile_n == 0 && howo % wm_rows == 0 &&
-                     a.gn_nchunk == howo / wm_rows && !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
-                 "igemm: GroupNorm statistics need full tiles of 128/160 columns holding whole groups, whole-wave row blocks "
-                 "inside one sample (Ho*Wo %% %d == 0, gn_nchunk == Ho*Wo / %d), N == 32 groups, no split-K", wm_rows, wm_rows);
-  }
   int rc;
   // LDS-DMA ring kernel (igemm_dma.hip) for 128-row tiles; the register-staged kernel below keeps
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
@@ -389,6 +441,22 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     a.splitk = halo_ns;
     DADD_REQUIRE(halo_ns == 1 || a.partial != nullptr, "igemm: split-K needs a partial buffer");
   }
+  if ((a.flags & DADD_EPI_GNSTAT) && (halo ? halo_ns : nsplit) > 1) {
+    // split-K: the finish kernel writes the partials, per 64-row chunk and 160- (or 128-) column block of whole groups
+    const int cb = (a.N % 160 == 0) ? 160 : 128, howo = a.Ho * a.Wo;
+    DADD_REQUIRE(a.gn_ws && a.gn_cg > 0 && a.N == 32 * a.gn_cg && !geglu && a.counters == nullptr && a.N % cb == 0 &&
+                     cb % a.gn_cg == 0 && a.M % 64 == 0 && howo % 64 == 0 && a.gn_nchunk == howo / 64 &&
+                     !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
+                 "igemm: GroupNorm statistics with split-K need the finish kernel (no tickets), N == 32 groups in blocks of "
+                 "160 / 128 columns, Ho*Wo %% 64 == 0 and gn_nchunk == Ho*Wo / 64");
+  } else if (a.flags & DADD_EPI_GNSTAT) {
+    const int wm_rows = tile_m / 2, wn_cols = tile_n / 2, howo = a.Ho * a.Wo;
+    DADD_REQUIRE(a.gn_ws && a.gn_cg > 0 && a.N == 32 * a.gn_cg && !geglu && (tile_n == 128 || tile_n == 160) &&
+                     wn_cols % a.gn_cg == 0 && a.M % tile_m == 0 && a.N % tile_n == 0 && howo % wm_rows == 0 &&
+                     a.gn_nchunk == howo / wm_rows && !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
+                 "igemm: GroupNorm statistics need full tiles of 128/160 columns holding whole groups, whole-wave row blocks "
+                 "inside one sample (Ho*Wo %% %d == 0, gn_nchunk == Ho*Wo / %d), N == 32 groups, no split-K", wm_rows, wm_rows);
+  }
   if (halo)
     rc = dadd_launch_conv_halo(a, halo_ns, s);
   else if (dma)
@@ -403,8 +471,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     const int ns = halo ? halo_ns : nsplit;
-    dadd_launch({"splitk_finish_kernel", 0.0, (double)a.M * a.N * (4.0 * ns + 2.0 + ((a.flags & DADD_EPI_RESIDUAL) ? 2.0 : 0.0))},
-                splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, ns);
+    const DaddLaunchTag tag = {(a.flags & DADD_EPI_GNSTAT) ? "splitk_finish_gn_kernel" : "splitk_finish_kernel", 0.0,
+                               (double)a.M * a.N * (4.0 * ns + 2.0 + ((a.flags & DADD_EPI_RESIDUAL) ? 2.0 : 0.0))};
+    if (!(a.flags & DADD_EPI_GNSTAT))
+      dadd_launch(tag, splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, ns);
+    else if (a.N % 160 == 0)
+      dadd_launch(tag, splitk_finish_gn_kernel<160>, dim3(a.M / 64, a.N / 160), dim3(256), 0, s, a, ns);
+    else
+      dadd_launch(tag, splitk_finish_gn_kernel<128>, dim3(a.M / 64, a.N / 128), dim3(256), 0, s, a, ns);
     DADD_LAUNCH_CHECK();
   }
   return DADD_OK;

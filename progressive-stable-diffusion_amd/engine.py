@@ -259,12 +259,17 @@ class _Plan:
             sk = 1                      # the row statistics come from whole rows of A: no K slices
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None
         gkw = {}
-        if gn_stats and GN_FROM_EPILOGUE and sk == 1 and not (flags & L.EPI_GEGLU) and n % 32 == 0:
-            howo, wm_rows, cg = out_shape[1] * out_shape[2], tile_m // 2, n // 32
+        if gn_stats and GN_FROM_EPILOGUE and not (flags & L.EPI_GEGLU) and n % 32 == 0:
+            howo, cg = out_shape[1] * out_shape[2], n // 32
+            if sk == 1:     # the GEMM's own epilogue writes the partials: one chunk per MFMA wave's row block
+                wm_rows = tile_m // 2
+                ok = tile_n in (128, 160) and (tile_n // 2) % cg == 0 and m % tile_m == 0 and n % tile_n == 0
+            else:           # split-K: the finish kernel writes them, per 64 rows x 160 (128) columns
+                wm_rows, cb = 64, (160 if n % 160 == 0 else 128)
+                ok = n % cb == 0 and cb % cg == 0 and m % 64 == 0
             nchunk = howo // wm_rows
             # (maps whose (batch, group) slab fits the single-launch LDS GroupNorm keep that path)
-            if (tile_n in (128, 160) and (tile_n // 2) % cg == 0 and m % tile_m == 0 and n % tile_n == 0
-                    and howo % wm_rows == 0 and 1 <= nchunk <= 128 and howo * cg * 2 > GN_FUSED_MAX_BYTES):
+            if ok and howo % wm_rows == 0 and 1 <= nchunk <= 128 and howo * cg * 2 > GN_FUSED_MAX_BYTES:
                 ws = self.be.zeros((out_shape[0] * nchunk * GROUPS * 2,), F32)
                 self.keep.append(ws)
                 self.gn_partials[out.data_ptr()] = (ws, nchunk)

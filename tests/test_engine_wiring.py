@@ -282,7 +282,15 @@ def test_groupnorm_statistics_from_the_producing_epilogue(monkeypatch):
     assert (y.float() - ref).abs().max().item() < 4e-3
     plan.pool.put(out)                                   # a recycled buffer must not keep its statistics
     assert out.data_ptr() not in plan.gn_partials
-    # split-K, 64-column tiles or a ragged tile count: no partials, the GroupNorm computes its own statistics
+    # split-K: the finish kernel writes the partials (64-row chunks); 64-column tiles: no partials, two-pass GroupNorm
     monkeypatch.setitem(E.TILING_OVERRIDE, E.tiling_key(b * hw * hw, cout, 9 * cin, 9, False, True), (128, 160, 2, 0))
     out2 = plan.conv(x, w, (b, hw, hw, cout), bias=bias, residual=res, gn_stats=True)
-    assert out2.data_ptr() not in plan.gn_partials
+    assert plan.gn_partials[out2.data_ptr()][1] == hw * hw // 64
+    y2 = plan.gn(out2, None, gamma, beta, 1e-5, 1)
+    plan.ops[-2][0](*plan.ops[-2][1], **plan.ops[-2][2])
+    plan.ops[-1][0](*plan.ops[-1][1], **plan.ops[-1][2])
+    assert (y2.float() - ref).abs().max().item() < 4e-3
+    w1 = (torch.randn(cout, cin, generator=g) / 8).to(torch.float16)
+    monkeypatch.setitem(E.TILING_OVERRIDE, E.tiling_key(b * hw * hw, cout, cin, 1, False, False), (64, 64, 1, 0))
+    out3 = plan.conv(x, w1, (b, hw, hw, cout), taps=1, pad=0, gn_stats=True)
+    assert out3.data_ptr() not in plan.gn_partials

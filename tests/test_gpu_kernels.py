@@ -641,6 +641,21 @@ def test_igemm_groupnorm_statistics_epilogue(hip, case):
     hip.groupnorm(o, None, dev(hip, gamma), dev(hip, beta), y2, ws2, 32, 1e-5, 1)
     hip.synchronize()
     close(y1, y2.float().cpu(), 2e-3, 2e-3, f"gn from partials {case}")
-    with pytest.raises(ValueError):        # contract: no split-K with epilogue statistics
+    # split-K: the finish kernel writes the partials (64-row chunks, blocks of 160 / 128 columns)
+    nch2 = hw * hw // 64
+    ws3 = hip.zeros((b * nch2 * 64,), F32)
+    o3 = hip.zeros((b, hw, hw, n), F16)
+    hip.igemm(dev(hip, x), dev(hip, w), o3, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=taps,
+              pad=taps // 9, flags=7 | L.EPI_GNSTAT | (tune & ~L.TUNE_NODMA), tile_m=tm, tile_n=tn, gn_ws=ws3, gn_nchunk=nch2,
+              splitk=2, partial=hip.zeros((2 * b * hw * hw * n,), F32))
+    y3 = hip.zeros((b, hw, hw, n), F16)
+    hip.groupnorm(o3, None, dev(hip, gamma), dev(hip, beta), y3, ws3, 32, 1e-5, 1, ws_chunks=nch2)
+    hip.synchronize()
+    close(o3, o_ref, 3e-3, 2e-3, f"gnstat split-K out {case}")
+    oc3 = o3.float().cpu().reshape(b, nch2, -1, 32, n // 32)
+    part3 = torch.stack([oc3.sum(dim=(2, 4)), (oc3 * oc3).sum(dim=(2, 4))], dim=-1)
+    assert (ws3.cpu().reshape(b, nch2, 32, 2) - part3).abs().max().item() <= 1e-3 * part3.abs().max().item() + 1e-3
+    close(y3, y2.float().cpu(), 3e-3, 3e-3, f"gn from finish partials {case}")
+    with pytest.raises(ValueError):        # contract: the chunk count must match the path that writes the partials
         hip.igemm(dev(hip, x), dev(hip, w), o, taps=taps, pad=taps // 9, flags=L.EPI_GNSTAT, tile_m=tm, tile_n=tn,
-                  gn_ws=ws, gn_nchunk=nchunk, splitk=2, partial=hip.zeros((2 * b * hw * hw * n,), F32))
+                  gn_ws=ws, gn_nchunk=nchunk + 1)
