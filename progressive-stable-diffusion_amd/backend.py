@@ -17,7 +17,13 @@ from . import lib as L
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    """Device pointer of a tensor argument.  A host tensor here would hand the kernel a host address (a GPU memory
+    fault, which can take the whole node down): refuse it as an ordinary Python error instead."""
+    if t is None:
+        return None
+    if t.device.type != "cuda":
+        raise ValueError(f"kernel argument lives on {t.device}, not on the GPU (shape {tuple(t.shape)}, {t.dtype})")
+    return t.data_ptr()
 
 
 class HipBackend:

@@ -442,7 +442,8 @@ class DiffusionModuleWithIP:
     def _q_sample(self, x0: torch.Tensor, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
         """(:299-303) forward diffusion on the HIP kernel."""
         be = self.be
-        x0, noise = x0.float().contiguous(), noise.float().contiguous()
+        x0 = x0.to(device=self.device, dtype=torch.float32).contiguous()
+        noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
         t = t.to(device=self.device, dtype=torch.long).contiguous()
         be.wait_current()
         out = be.empty(tuple(x0.shape), torch.float32)
