@@ -658,4 +658,4 @@ def test_igemm_groupnorm_statistics_epilogue(hip, case):
     close(y3, y2.float().cpu(), 3e-3, 3e-3, f"gn from finish partials {case}")
     with pytest.raises(ValueError):        # contract: the chunk count must match the path that writes the partials
         hip.igemm(dev(hip, x), dev(hip, w), o, taps=taps, pad=taps // 9, flags=L.EPI_GNSTAT, tile_m=tm, tile_n=tn,
-                  gn_ws=ws, gn_nchunk=nchunk + 1)
+                  gn_ws=hip.zeros((b * (nchunk + 1) * 64,), F32), gn_nchunk=nchunk + 1)
