@@ -38,6 +38,10 @@ extern "C" {
 #define DADD_EPI_LNFOLD 128 /* a LayerNorm over the K (= channel) axis of x folded into this linear: w carries gamma,
                               bias the composed (w beta + b), ln_c1[n] = sum_k w[n][k]; the kernel derives the row
                               mean / rstd from the A fragments it reads anyway: out = rstd (acc - mu c1) + bias */
+#define DADD_EPI_LNSTAT 4096 /* the epilogue also writes the LayerNorm ROW partials of its OUTPUT (sum, sum of squares of the
+                               rounded fp16 values over each block of tile_n/2 columns) into ln_stats_out [ln_parts][M][2],
+                               ln_parts = N / (tile_n/2): the linear that consumes LayerNorm(out) takes them through
+                               ln_stats_in and needs neither a LayerNorm launch nor statistics of its own */
 #define DADD_EPI_GNSTAT 2048 /* the epilogue also writes the GroupNorm chunk partials of its OUTPUT (32 groups) into
                                gn_ws [B][gn_nchunk][32][2] (sum, sum of squares per row block of tile_m/2 rows): the
                                consuming dadd_groupnorm_f16 then skips its statistics pass (ws_chunks = gn_nchunk) */
@@ -95,6 +99,10 @@ typedef struct {
   float ln_eps;
   float* gn_ws;                  /* DADD_EPI_GNSTAT (see the flag) */
   int32_t gn_nchunk, gn_cg;      /*   chunks per sample = Ho*Wo / (tile_m/2); channels per group = N / 32 */
+  float* ln_stats_out;           /* DADD_EPI_LNSTAT (see the flag): [ln_parts_out][M][2] floats */
+  const float* ln_stats_in;      /* with DADD_EPI_LNFOLD: row partials [ln_parts_in][M][2] of x written by the GEMM that
+                                    produced x (its DADD_EPI_LNSTAT); NULL: the kernel sums the rows itself */
+  int32_t ln_parts_out, ln_parts_in;
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 
@@ -183,9 +191,12 @@ int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* ga
  * vw [B][C][384]: column (h*3+p)*16+t = gate_p * W_o[:, h*d:(h+1)*d] . V_p[b,t,h,:]  (gate_2 = lambda);
  * out = softmax16(x mcat^T) vw^T + bias + residual, 24 independent 16-wide softmaxes per token.
  * H*W % 128 == 0, C % 320 == 0.  Replaces to_q + SplitInjectionAttentionProcessor.__call__:142-181 + to_out
- * (src/models/attention_processor_routing_gates.py:118-190) — exact algebra, other rounding points. */
+ * (src/models/attention_processor_routing_gates.py:118-190) — exact algebra, other rounding points.
+ * ln_stats_out (or NULL): LayerNorm row partials of `out`, [C / 80][B*HW][2] floats, as DADD_EPI_LNSTAT writes them
+ * (the GEGLU projection behind norm3 then takes them through ln_stats_in). */
 int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const float* bias,
-                         const void* residual, void* out, int B, int HW, int C, void* stream);
+                         const void* residual, void* out, float* ln_stats_out, int B, int HW, int C,
+                         void* stream);
 
 /* ---- sampler glue --------------------------------------------------------------------------
  * Sinusoidal timestep features (flip_sin_to_cos, shift 0): out[m][0:dim/2]=cos, [dim/2:]=sin. */

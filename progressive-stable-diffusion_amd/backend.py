@@ -126,8 +126,10 @@ class HipBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5, gn_ws=None, gn_nchunk=0):
-        """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU)."""
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None):
+        """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU).
+        ``ln_stats_out`` [P][M][2] fp32 (EPI_LNSTAT): row partials of the output, P = N / (tile_n/2);
+        ``ln_stats_in`` [P'][M][2] (EPI_LNFOLD): the partials of x written by its producer."""
         b, hi, wi, c1 = x.shape
         c2 = 0 if x2 is None else x2.shape[-1]
         n = w.shape[0]
@@ -149,6 +151,16 @@ class HipBackend:
             assert flags & L.EPI_GNSTAT and gn_ws.numel() >= b * gn_nchunk * 64 and gn_ws.dtype == torch.float32
         if ln_c1 is not None:
             assert flags & L.EPI_LNFOLD and ln_c1.numel() == n and ln_c1.dtype == torch.float32
+        m_rows = b * ho * wo
+        d.ln_stats_out, d.ln_stats_in, d.ln_parts_out, d.ln_parts_in = _p(ln_stats_out), _p(ln_stats_in), 0, 0
+        if ln_stats_out is not None:
+            assert flags & L.EPI_LNSTAT and ln_stats_out.dtype == torch.float32 and ln_stats_out.dim() == 3 \
+                and ln_stats_out.shape[1:] == (m_rows, 2) and ln_stats_out.is_contiguous()
+            d.ln_parts_out = ln_stats_out.shape[0]
+        if ln_stats_in is not None:
+            assert flags & L.EPI_LNFOLD and ln_stats_in.dtype == torch.float32 and ln_stats_in.dim() == 3 \
+                and ln_stats_in.shape[1:] == (b * hi * wi, 2) and ln_stats_in.is_contiguous()
+            d.ln_parts_in = ln_stats_in.shape[0]
         if partial is not None:
             assert partial.numel() >= splitk * b * ho * wo * n
         L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))
@@ -184,11 +196,15 @@ class HipBackend:
                                             b, n, heads, c // heads, kv.shape[1], kv.stride(1),
                                             self.s))
 
-    def attn2_fused(self, x, mcat, vw, bias, residual, out):
-        """x, residual, out [B,HW,C]; mcat [B,384,C]; vw [B,C,384] (include/dadd_hip.h)."""
+    def attn2_fused(self, x, mcat, vw, bias, residual, out, ln_stats_out=None):
+        """x, residual, out [B,HW,C]; mcat [B,384,C]; vw [B,C,384] (include/dadd_hip.h); ``ln_stats_out`` [C/80][B*HW][2]
+        fp32: LayerNorm row partials of ``out`` for the linear behind the next LayerNorm."""
         b, hw, c = x.shape
         assert mcat.shape == (b, 384, c) and vw.shape == (b, c, 384) and out.shape == x.shape
-        L.check(self.lib.dadd_attn2_fused_f16(_p(x), _p(mcat), _p(vw), _p(bias), _p(residual), _p(out),
+        if ln_stats_out is not None:
+            assert ln_stats_out.shape == (c // 80, b * hw, 2) and ln_stats_out.dtype == torch.float32 \
+                and ln_stats_out.is_contiguous()
+        L.check(self.lib.dadd_attn2_fused_f16(_p(x), _p(mcat), _p(vw), _p(bias), _p(residual), _p(out), _p(ln_stats_out),
                                               b, hw, c, self.s))
 
     def timestep_features(self, t, out):

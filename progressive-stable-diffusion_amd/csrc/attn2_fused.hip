@@ -44,6 +44,7 @@ struct Attn2Args {
   const float* bias;       // [C] or null
   const half_t* residual;  // [B*HW][C]
   half_t* out;             // [B*HW][C]
+  float* ln_stats;         // null, or LayerNorm row partials of `out`: [C / 80][B*HW][2] (DADD_EPI_LNSTAT of igemm)
   int B, HW, C;
 };
 
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const size_t m = (size_t)m0 + wm * WMR + i * 16 + mc;
+        float rs1 = 0.f, rs2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const int n = nt * BN2 + wn * 80 + j * 16 + g * 4;
@@ -222,6 +224,20 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
           const h4 o = {(half_t)(v[0] + (float)rv[0]), (half_t)(v[1] + (float)rv[1]),
                         (half_t)(v[2] + (float)rv[2]), (half_t)(v[3] + (float)rv[3])};
           *reinterpret_cast<h4*>(p.out + m * C + n) = o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float f = (float)o[r];
+            rs1 += f;
+            rs2 = fmaf(f, f, rs2);
+          }
+        }
+        if (p.ln_stats) {     // the next LayerNorm's row partials (sum, sum of squares over this wave's 80 columns)
+          rs1 += __shfl_xor(rs1, 16, 64);
+          rs2 += __shfl_xor(rs2, 16, 64);
+          rs1 += __shfl_xor(rs1, 32, 64);
+          rs2 += __shfl_xor(rs2, 32, 64);
+          if (g == 0)
+            reinterpret_cast<dadd_f2*>(p.ln_stats)[(size_t)(nt * 2 + wn) * ((size_t)p.B * p.HW) + m] = dadd_f2{rs1, rs2};
         }
       }
     }
@@ -245,7 +261,8 @@ int dadd_init_attn2_fused() {
 }
 
 extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const float* bias,
-                                    const void* residual, void* out, int B, int HW, int C, void* stream) {
+                                    const void* residual, void* out, float* ln_stats_out, int B, int HW, int C,
+                                    void* stream) {
   DADD_REQUIRE(x && mcat && vw && residual && out, "attn2_fused: null pointer");
   DADD_REQUIRE(B > 0 && HW > 0 && HW % 128 == 0, "attn2_fused: H*W=%d must be a multiple of 128", HW);
   DADD_REQUIRE(C > 0 && C % BN2 == 0 && C % BK == 0, "attn2_fused: C=%d must be a multiple of 320", C);
@@ -260,6 +277,7 @@ extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void*
   a.bias = bias;
   a.residual = static_cast<const half_t*>(residual);
   a.out = static_cast<half_t*>(out);
+  a.ln_stats = ln_stats_out;
   a.B = B; a.HW = HW; a.C = C;
   // algorithmic work: two GEMMs against the folded conditioning (K = C, N = 384 and K = 384, N = C)
   const double flop = 4.0 * (double)B * HW * C * 384.0;

@@ -79,6 +79,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
 
+  // folded LayerNorm with the producer's row partials: its operands are staged behind the two K-tile buffers (ln_lds.h)
+  char* const ln_scr = smem + 2 * (BM + BN) * BK * 2;
+  constexpr int LN_CAP = BM == 128 ? (BN == 160 ? 8192 : LN_LDS_BYTES) : 4096;   // two workgroups per CU stay resident
+  bool ln_stage = false, ln_sts = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+  ln_stage = ln_lds_usable(p, BM, 3);
+  ln_sts = ln_stage && ln_lds_stats(p, LN_CAP);
+  if (ln_stage) ln_lds_issue<BN>(p, ln_scr, m0, n0, __builtin_amdgcn_readfirstlane(wave), lane, ln_sts);
+#endif
+
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto gload = [&](int kt, h8 (&ra)[NA], h8 (&rb)[NB]) {
     const int kk = kt * BK;
@@ -181,7 +191,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
   }
 
   // ---- epilogue (shared with igemm_dma.hip): lane holds out[m][n .. n+3] of the swapped MFMA result
-  igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + 2 * (BM + BN) * BK * 2);
+  if (ln_stage) {     // (the DMA are the oldest vector-memory operations of every wave)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  igemm_epilogue<J, MI, WM, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, ln_scr, ln_sts ? ln_scr + LN_LDS_STATS : nullptr,
+                                ln_stage ? ln_scr : nullptr);
 }
 
 // Finishes a split-K launch: sums the fp32 slabs and applies the (non-GEGLU) epilogue.
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(256) void splitk_finish_gn_kernel(const IgemmArgs p
 
 template <int BM, int BN, bool DEEP>
 int set_attr() {
-  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;
+  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + (BM == 128 ? (BN == 160 ? 8192 : LN_LDS_BYTES) : 4096);
   DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, DEEP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
@@ -293,7 +308,7 @@ int set_attr() {
 
 template <int BM, int BN, bool DEEP>
 int launch(const IgemmArgs& a, int nsplit, hipStream_t s) {
-  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + 4096;   // + the epilogue's statistics scratch
+  constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + (BM == 128 ? (BN == 160 ? 8192 : LN_LDS_BYTES) : 4096);   // + the epilogue's scratch
   const int mtiles = (a.M + BM - 1) / BM;
   dim3 grid(mtiles * a.ntiles, nsplit);
   static const std::string name = "igemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + (DEEP ? "true" : "false") + ">";
@@ -338,12 +353,15 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK | DADD_EPI_GNSTAT);
+  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK | DADD_EPI_GNSTAT | DADD_EPI_LNSTAT);
   a.gn_ws = d->gn_ws;
   a.gn_nchunk = d->gn_nchunk;
   a.gn_cg = d->gn_cg;   // epilogue bits + the persistent-ring request
   a.ln_c1 = d->ln_c1;
   a.ln_eps = d->ln_eps;
+  a.ln_stats_out = d->ln_stats_out;
+  a.ln_stats_in = (a.flags & DADD_EPI_LNFOLD) ? d->ln_stats_in : nullptr;
+  a.ln_parts_in = d->ln_parts_in;
   const int Cin = a.C1 + a.C2;
   const bool geglu = (a.flags & DADD_EPI_GEGLU) != 0;
   a.ldo = d->ldo > 0 ? d->ldo : (geglu ? a.N / 2 : a.N);
@@ -370,6 +388,7 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                "igemm: an activation epilogue excludes GEGLU and split-K");
   DADD_REQUIRE(!(a.flags & DADD_EPI_LNFOLD) || (a.ln_c1 && a.taps == 1 && a.C2 == 0 && d->splitk <= 1 && a.ln_eps > 0.f),
                "igemm: a folded LayerNorm needs c1, a plain linear over one source (K = C) and no split-K");
+  DADD_REQUIRE(a.ln_stats_in == nullptr || a.ln_parts_in > 0, "igemm: ln_stats_in needs ln_parts_in > 0");
   DADD_REQUIRE(a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ld_rowvec % 4 == 0,
                "igemm: leading dimensions must be multiples of 4");
 
@@ -419,7 +438,9 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   // the 64-row tiles and serves as the A/B reference (DADD_TUNE_NODMA)
   // (the 64-row LDS-DMA tiles have no upsample gather: such a request runs on the register-staged kernel; a folded
   // LayerNorm exists on the LDS-DMA kernel only)
-  const bool dma = ((d->flags & DADD_TUNE_NODMA) == 0 || (a.flags & DADD_EPI_LNFOLD)) && !(tile_m == 64 && a.ups);
+  // (... unless its row statistics come from the producer of x: then the fold is epilogue arithmetic on every kernel)
+  const bool dma = ((d->flags & DADD_TUNE_NODMA) == 0 || ((a.flags & DADD_EPI_LNFOLD) && !a.ln_stats_in)) &&
+                   !(tile_m == 64 && a.ups);
   DADD_REQUIRE(tile_n != 64 || (dma && tile_m == 64 && !geglu), "igemm: 64-column tiles exist for the 64-row LDS-DMA kernel only");
   // persistent ring: a workgroup walks a contiguous run of tiles.  Activation-heavy GEMMs: column tile fastest, the
   // run keeps ONE activation row tile (L2-hot after the first tile) and streams the (L2-resident) weight tiles.
@@ -456,6 +477,13 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                      a.gn_nchunk == howo / wm_rows && !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
                  "igemm: GroupNorm statistics need full tiles of 128/160 columns holding whole groups, whole-wave row blocks "
                  "inside one sample (Ho*Wo %% %d == 0, gn_nchunk == Ho*Wo / %d), N == 32 groups, no split-K", wm_rows, wm_rows);
+  }
+  if (a.flags & DADD_EPI_LNSTAT) {
+    const int wn_cols = tile_n / 2;
+    DADD_REQUIRE(a.ln_stats_out && !geglu && !halo && a.N % wn_cols == 0 && d->ln_parts_out == a.N / wn_cols &&
+                     (nsplit == 1 || a.counters != nullptr) && !(a.flags & DADD_EPI_GNSTAT),
+                 "igemm: LayerNorm row partials need ln_stats_out, N %% (tile_n/2) == 0, ln_parts_out == N / (tile_n/2) = %d, "
+                 "no GEGLU and no finish-kernel split-K", a.N / wn_cols);
   }
   if (halo)
     rc = dadd_launch_conv_halo(a, halo_ns, s);

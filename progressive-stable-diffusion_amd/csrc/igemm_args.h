@@ -16,6 +16,9 @@ struct IgemmArgs {
   int gn_nchunk, gn_cg;  //   chunks per sample (= Ho*Wo / rows per MFMA wave), channels per group
   const float* ln_c1;   // DADD_EPI_LNFOLD: c1[n] = sum_k w[n][k] (w already carries the LayerNorm gamma)
   float ln_eps;
+  float* ln_stats_out;        // DADD_EPI_LNSTAT: row partials of the OUTPUT, [N / WN][M][2] (WN = columns per MFMA wave)
+  const float* ln_stats_in;   // DADD_EPI_LNFOLD with the statistics of x supplied by its producer: [ln_parts_in][M][2]
+  int ln_parts_in;
   int B, Hi, Wi, C1, C2, Ho, Wo, N;
   int taps, stride, ups, pad;
   int ldo, ldr, ld_rowvec;

@@ -255,18 +255,52 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
   // this workgroup's output tiles (the cursor rolls over inside issue(), including the per-tile address
   // setup — off the MFMA waves).
   const int total_kt = tile_count * nk;
+  // Folded LayerNorm with the producer's row partials (ln_lds.h): the operands of a tile's epilogue are staged in the
+  // scratch behind the ring by the LOADER waves, as extra DMA behind the K tile they issue right after the barrier
+  // that opens the output tile (every MFMA wave has then left the previous tile's epilogue, which read the scratch).
+  // The counted wait of the next iteration allows for them (LPT + extras youngest operations may be in flight); one
+  // iteration later they are as old as the K tile issued with them and the plain wait covers both.  nk >= 3, so the
+  // barrier that publishes them precedes the tile's epilogue.
+  char* const ln_scr = smem + 4 * STAGE;
+  const bool ln_stage = !LNF && !UPS && ln_lds_usable(p, BM, nk);
+  const bool ln_sts = ln_stage && ln_lds_stats(p, LN_LDS_BYTES);
   if (loader) {
+    const int ln_extra = ln_stage ? ln_lds_count(p, wave, ln_sts) : 0;      // extras this wave issues per output tile
     issue();
     issue();
     issue();
     wait_vmcnt<LPT>();
     __builtin_amdgcn_s_barrier();
+    bool ext_young = false;
+    int kc = 0, ext_tile = tile_first;
     for (int it = 0; it < total_kt; ++it) {
       if (it > 0) {
-        wait_vmcnt<LPT>();   // tile it+1 landed (this wave's share); tile it+2 may be in flight
+        if (ext_young) {     // wave-uniform
+          switch (ln_extra) {
+            case 1: wait_vmcnt<LPT + 1>(); break;
+            case 2: wait_vmcnt<LPT + 2>(); break;
+            case 3: wait_vmcnt<LPT + 3>(); break;
+            case 4: wait_vmcnt<LPT + 4>(); break;
+            default: wait_vmcnt<LPT>(); break;
+          }
+          ext_young = false;
+        } else {
+          wait_vmcnt<LPT>();   // tile it+1 landed (this wave's share); tile it+2 may be in flight
+        }
         __builtin_amdgcn_s_barrier();
       }
       issue();               // tile it+3 -> the slot of tile it-1, free since this barrier
+      if (ln_stage) {
+        if (kc == 0) {
+          int nt, mt;
+          tile_decode(p, ext_tile, mt, nt);
+          ln_lds_issue<BN>(p, ln_scr, __builtin_amdgcn_readfirstlane(mt) * BM, __builtin_amdgcn_readfirstlane(nt) * BN, wave,
+                           lane, ln_sts);
+          ext_young = ln_extra > 0;
+          ++ext_tile;
+        }
+        kc = kc + 1 == nk ? 0 : kc + 1;
+      }
     }
     wait_vmcnt<0>();
     return;
@@ -351,14 +385,17 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
       ln_finish<MI>(ls1, ls2, p.K, p.ln_eps);
       igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem, ls1, ls2);
     } else {
-      igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem, nullptr, nullptr, smem + 4 * STAGE);
+      igemm_epilogue<J, MI, WM, WN>(p, acc, mt * BM, nt * BN, wm, wn, lane, z, smem, nullptr, nullptr, smem + 4 * STAGE,
+                                    ln_sts ? ln_scr + LN_LDS_STATS : nullptr, ln_stage ? ln_scr : nullptr);
     }
   }
 #endif
 }
 
 template <int BM, int BN>
-constexpr int smem_bytes() { return 4 * (BM + BN) * BK * 2 + 4096; }   // ring + the epilogue's statistics scratch
+constexpr int smem_bytes() {   // ring + the epilogue's scratch (GroupNorm partials; 128-row tiles: the staged LayerNorm operands)
+  return 4 * (BM + BN) * BK * 2 + (BM == 128 ? LN_LDS_BYTES : 4096);
+}
 
 template <int BM, int BN, bool UPS, bool PERS, bool LNF>
 int set_attr() {
@@ -378,7 +415,7 @@ void launch1(const char* name, const IgemmArgs& a, dim3 grid, hipStream_t s) {
 template <int BM, int BN, bool UPS, bool PERS>
 void launch(const char* name, const char* name_ln, const IgemmArgs& a, dim3 grid, hipStream_t s) {
   if constexpr (!UPS) {
-    if (a.flags & DADD_EPI_LNFOLD) {
+    if ((a.flags & DADD_EPI_LNFOLD) && a.ln_stats_in == nullptr) {     // the kernel sums the rows itself
       launch1<BM, BN, false, PERS, true>(name_ln, a, grid, s);
       return;
     }

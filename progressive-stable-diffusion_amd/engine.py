@@ -99,6 +99,12 @@ GN_FUSED_MAX_BYTES = 16 * 1024       # csrc/norm.hip: below this slab size the s
 # critical path (qkv 64x64: 45 vs 26 us).  So "auto" folds exactly the linears planned on 64-row tiles; True / False
 # force it everywhere / nowhere (tests, A/B measurements).
 LN_FOLD = "auto"
+# ... and on the 128-row tiles the fold is epilogue arithmetic only when the row statistics come from the GEMM that
+# produced the hidden states (DADD_EPI_LNSTAT partials of its output, csrc/igemm_epilogue.h): no LayerNorm launch, no
+# normalised copy, no statistics in the consumer's K loop.
+LN_STATS_FROM_PRODUCER = True
+LN_STATS_MAX_PARTS = 8          # what the consumer stages in LDS (csrc/ln_lds.h); more parts (1280 channels from 64-column
+                                # tiles: 40) would be read from global memory in the epilogue — slower than the LayerNorm launch
 
 
 def fold_here(m: int, n: int, k: int, geglu: bool = False) -> bool:
@@ -212,7 +218,12 @@ class _Plan:
         self.ops: List = []
         self.keep: List[torch.Tensor] = []  # weights & persistent buffers
         self.gn_partials: Dict[int, Tuple[torch.Tensor, int]] = {}   # output buffer -> (chunk partials, chunks)
-        self.pool.on_put = lambda t: self.gn_partials.pop(t.data_ptr(), None)   # a recycled buffer loses its statistics
+        self.ln_partials: Dict[int, torch.Tensor] = {}               # output buffer -> LayerNorm row partials [P][M][2]
+
+        def _forget(t):                 # a recycled buffer loses its statistics
+            self.gn_partials.pop(t.data_ptr(), None)
+            self.ln_partials.pop(t.data_ptr(), None)
+        self.pool.on_put = _forget
         self.gn_ws = None
         # Split-K slabs are combined by the finish kernel.  The in-launch combine (last-arriving slice
         # reduces; `counters` of dadd_conv_igemm_f16) is implemented and tested but measured 2-4x SLOWER
@@ -246,8 +257,12 @@ class _Plan:
 
     # ---- recorded building blocks -----------------------------------------------------------
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
-             stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5, gn_stats=False):
-        """``gn_stats``: the output feeds a GroupNorm — have the epilogue write its chunk partials (DADD_EPI_GNSTAT)
+             stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5, gn_stats=False, ln_stats=False,
+             ln_stats_in=None):
+        """``ln_stats``: the output feeds a LayerNorm whose consumer is a folded linear — have the epilogue write the row
+        partials (DADD_EPI_LNSTAT) where the launch allows (plain linear, one K pass, whole wave column blocks); they
+        are found again through ``self.ln_partials``.  ``ln_stats_in``: such partials of ``x`` for this folded linear.
+        ``gn_stats``: the output feeds a GroupNorm — have the epilogue write its chunk partials (DADD_EPI_GNSTAT)
         where the tiling allows (full 128/160-column tiles holding whole groups, row blocks inside one sample, <= 128
         chunks, no split-K); the consuming ``gn()`` then skips its statistics pass."""
         out = self.pool.get(out_shape)
@@ -275,9 +290,18 @@ class _Plan:
                 self.gn_partials[out.data_ptr()] = (ws, nchunk)
                 gkw = dict(gn_ws=ws, gn_nchunk=nchunk)
                 flags |= L.EPI_GNSTAT
+        if (ln_stats and LN_STATS_FROM_PRODUCER and not (flags & (L.EPI_GEGLU | L.EPI_GNSTAT)) and sk == 1
+                and n % (tile_n // 2) == 0 and n // (tile_n // 2) <= LN_STATS_MAX_PARTS):
+            st = self.be.zeros((n // (tile_n // 2), m, 2), F32)
+            self.keep.append(st)
+            self.ln_partials[out.data_ptr()] = st
+            gkw["ln_stats_out"] = st
+            flags |= L.EPI_LNSTAT
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | (L.EPI_LNFOLD if ln_c1 is not None else 0) | tune
         kw = dict(ln_c1=ln_c1, ln_eps=ln_eps) if ln_c1 is not None else {}
+        if ln_c1 is not None and ln_stats_in is not None:
+            kw["ln_stats_in"] = ln_stats_in
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
                  taps=taps, stride=stride, ups=ups, pad=pad, flags=f, splitk=sk, partial=partial,
                  tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None, **kw, **gkw)  # None: finish kernel
@@ -447,51 +471,66 @@ class UNetPlan(_Plan):
                                fold_here(m_rows, 8 * c, c, True))
         g = self.gn(x, None, self.f(site + ".norm.weight"), self.f(site + ".norm.bias"), 1e-6, 0)
         hs = self.conv(g, self.w(site + ".proj_in.weight"), shp, bias=self.f(site + ".proj_in.bias"),
-                       taps=1, pad=0)
+                       taps=1, pad=0, ln_stats=LN_STATS_FROM_PRODUCER and LN_FOLD == "auto" and not fold1)
         self.pool.put(g)
-        need_ln = not (fold1 and fold2 and fold3)      # (the fused attn2 kernel reads a normalised copy)
-        ln = self.pool.get(shp) if need_ln else None
+        ext = LN_STATS_FROM_PRODUCER and LN_FOLD == "auto"
+        ln_box = [None]                 # the normalised copy, allocated only if some LayerNorm still runs as a kernel
+
+        def ln_of(src, norm):
+            if ln_box[0] is None:
+                ln_box[0] = self.pool.get(shp)
+            self.rec(self.be.layernorm, src, self.f(tb + norm + ".weight"), self.f(tb + norm + ".bias"), ln_box[0])
+            return ln_box[0]
         # attn1 (self)
-        if fold1:
+        st1 = self.ln_partials.get(hs.data_ptr())
+        if fold1 or st1 is not None:
             wqkv, c1, bqkv = self._ln_linear(tb, ".norm1", "qkv", [f".attn1.to_{n}.weight" for n in "qkv"])
-            qkv = self.conv(hs, wqkv, (b, h, w_, 3 * c), bias=bqkv, taps=1, pad=0, ln_c1=c1)
+            qkv = self.conv(hs, wqkv, (b, h, w_, 3 * c), bias=bqkv, taps=1, pad=0, ln_c1=c1,
+                            ln_stats_in=None if fold1 else st1)
         else:
-            self.rec(self.be.layernorm, hs, self.f(tb + ".norm1.weight"), self.f(tb + ".norm1.bias"), ln)
             wqkv = self.cached((self.prefix + tb, "qkv"), lambda: self.dev(
                 torch.cat([self.sd[self.prefix + tb + f".attn1.to_{n}.weight"] for n in "qkv"]), F16))
-            qkv = self.conv(ln, wqkv, (b, h, w_, 3 * c), taps=1, pad=0)
+            qkv = self.conv(ln_of(hs, ".norm1"), wqkv, (b, h, w_, 3 * c), taps=1, pad=0)
         att = self.pool.get(shp)
         self.rec(self.be.self_attn, qkv.view(b, h * w_, 3 * c), att.view(b, h * w_, c), HEADS)
         self.pool.put(qkv)
+        fused2 = site in self.a2
         h2 = self.conv(att, self.w(tb + ".attn1.to_out.0.weight"), shp,
-                       bias=self.f(tb + ".attn1.to_out.0.bias"), residual=hs, taps=1, pad=0)
+                       bias=self.f(tb + ".attn1.to_out.0.bias"), residual=hs, taps=1, pad=0,
+                       ln_stats=ext and not fold2 and not fused2)
         self.pool.put(hs)
         # attn2 (DADD cross-attention)
-        if site in self.a2:          # one kernel: x (W_q K^T) -> 24 softmaxes -> P (V W_o^T) + bias + residual
-            self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
+        st3 = None
+        if fused2:                   # one kernel: x (W_q K^T) -> 24 softmaxes -> P (V W_o^T) + bias + residual
+            lnx = ln_of(h2, ".norm2")
             st = self.a2[site]
             h3 = self.pool.get(shp)
-            self.rec(self.be.attn2_fused, ln.view(b, h * w_, c), st["mcat"], st["vw"],
-                     self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c))
+            if ext and not fold3 and c % 80 == 0:
+                st3 = self.be.zeros((c // 80, m_rows, 2), F32)
+                self.keep.append(st3)
+            self.rec(self.be.attn2_fused, lnx.view(b, h * w_, c), st["mcat"], st["vw"],
+                     self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c),
+                     **({"ln_stats_out": st3} if st3 is not None else {}))
         else:
-            if fold2:
+            st2 = self.ln_partials.get(h2.data_ptr())
+            if fold2 or st2 is not None:
                 wq, c1, bq = self._ln_linear(tb, ".norm2", "to_q", [".attn2.to_q.weight"])
-                q = self.conv(h2, wq, shp, bias=bq, taps=1, pad=0, ln_c1=c1)
+                q = self.conv(h2, wq, shp, bias=bq, taps=1, pad=0, ln_c1=c1, ln_stats_in=None if fold2 else st2)
             else:
-                self.rec(self.be.layernorm, h2, self.f(tb + ".norm2.weight"), self.f(tb + ".norm2.bias"), ln)
-                q = self.conv(ln, self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
+                q = self.conv(ln_of(h2, ".norm2"), self.w(tb + ".attn2.to_q.weight"), shp, taps=1, pad=0)
             self.rec(self._xattn, site, q.view(b, h * w_, c), att.view(b, h * w_, c))
             self.pool.put(q)
             h3 = self.conv(att, self.w(tb + ".attn2.to_out.0.weight"), shp,
-                           bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0)
+                           bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0,
+                           ln_stats=ext and not fold3)
+            st3 = self.ln_partials.get(h3.data_ptr())
         self.pool.put(h2, att)
         # GEGLU feed-forward
-        if fold3:
+        if fold3 or st3 is not None:
             wf, c1, bf = self._ln_linear(tb, ".norm3", "geglu", [".ff.net.0.proj.weight"], ".ff.net.0.proj.bias", geglu=True)
-            ff = self.conv(h3, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU, ln_c1=c1)
+            ff = self.conv(h3, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU, ln_c1=c1,
+                           ln_stats_in=None if fold3 else st3)
         else:
-            self.rec(self.be.layernorm, h3, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"), ln)
-
             def _geglu():
                 wf, bf = geglu_interleave(self.sd[self.prefix + tb + ".ff.net.0.proj.weight"],
                                           self.sd[self.prefix + tb + ".ff.net.0.proj.bias"])
@@ -499,7 +538,8 @@ class UNetPlan(_Plan):
             wf, bf = self.cached((self.prefix + tb, "geglu"), _geglu)
             if self.wcache is not None:
                 self.keep += [wf, bf]
-            ff = self.conv(ln, wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU)
+            ff = self.conv(ln_of(h3, ".norm3"), wf, (b, h, w_, 4 * c), bias=bf, taps=1, pad=0, flags=L.EPI_GEGLU)
+        ln = ln_box[0]
         self.pool.put(ln)
         h4 = self.conv(ff, self.w(tb + ".ff.net.2.weight"), shp, bias=self.f(tb + ".ff.net.2.bias"),
                        residual=h3, taps=1, pad=0)

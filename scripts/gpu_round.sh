@@ -24,6 +24,8 @@ for s in $steps; do
     parity)  run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 ;;
     smoke)   run smoke 300 python __graft_entry__.py smoke ;;
     stepprof) TAILN=60 run stepprof 600 python scripts/step_profile.py --list --out "$out/step_profile.txt" ;;
+    stepprofab) TAILN=5 run stepprof_a 600 python scripts/step_profile.py --list --out "$out/step_profile_a.txt" --set LN_STATS_FROM_PRODUCER=False
+                TAILN=5 run stepprof_b 600 python scripts/step_profile.py --list --out "$out/step_profile_b.txt" ;;
     stepprofvae) TAILN=40 run stepprofvae 600 python scripts/step_profile.py --vae --list --out "$out/step_profile_vae.txt" ;;
     opbench) TAILN=80 run opbench 600 python scripts/op_bench.py "$tag" ;;
     opbenchvae) TAILN=60 run opbenchvae 600 python scripts/op_bench.py "$tag" --vae ;;

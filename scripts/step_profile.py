@@ -23,11 +23,19 @@ def main():
     ap.add_argument("--vae", action="store_true")
     ap.add_argument("--list", action="store_true", help="also print every launch of the last step in issue order")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="override an engine policy variable for an A/B on one box, e.g. --set LN_STATS_FROM_PRODUCER=False")
     a = ap.parse_args()
     from bench import kernel_table
     from progressive_stable_diffusion_amd import weights as W
     from progressive_stable_diffusion_amd.backend import HipBackend
+    from progressive_stable_diffusion_amd import engine as E
     from progressive_stable_diffusion_amd.engine import DdimLoop, UNetPlan, VaeDecoderPlan
+    import ast
+    for kv in a.set:
+        k, v = kv.split("=", 1)
+        assert hasattr(E, k), k
+        setattr(E, k, ast.literal_eval(v))
     dev = torch.device("cuda:0")
     be = HipBackend(dev)
     side = a.image_size // 8

@@ -103,6 +103,39 @@ def test_unet_plan_matches_oracle(unet_sd, lam, fold, monkeypatch):
     assert 0 <= n_auto <= 48
 
 
+@pytest.mark.parametrize("lam", [0.0, 3.0])
+def test_unet_plan_layernorm_statistics_from_producer(unet_sd, lam, monkeypatch):
+    """The other half of the "auto" policy: where the consumer does not sum the rows itself (128-row tiles on the GPU;
+    forced everywhere here), the GEMM that PRODUCES the hidden states writes the LayerNorm row partials
+    (DADD_EPI_LNSTAT / attn2_fused ln_stats_out) and the folded consumer reads them: only LayerNorm 2 in front of a
+    fused attn2 kernel is left as a launch, and the result is the oracle's."""
+    from progressive_stable_diffusion_amd import lib as L
+    monkeypatch.setattr(E, "LN_FOLD", "auto")
+    monkeypatch.setattr(E, "fold_here", lambda *a, **k: False)
+    monkeypatch.setattr(E, "LN_STATS_MAX_PARTS", 1000)     # (the small maps of this test run on 64-column tiles: 40 parts)
+    torch.manual_seed(1)
+    b, s = 2, 8
+    plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    x, cond = torch.randn(b, 4, s, s), torch.randn(b, 48, 768) * 0.5
+    t = torch.tensor([999, 333])
+    with torch.no_grad():
+        ref = unet_forward(unet_sd, x, t, cond, delta_scale=lam)
+        got = plan.forward(x, t, cond, lam=lam)
+    assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item())
+    names = [getattr(fn, "__name__", "") for fn, _, _ in plan.ops]
+    assert names.count("layernorm") == len(plan.a2)
+    n_out = sum(1 for fn, _, k in plan.ops if k.get("ln_stats_out") is not None)
+    n_in = sum(1 for fn, _, k in plan.ops if k.get("ln_stats_in") is not None)
+    assert n_in == 48 - len(plan.a2) and n_out == n_in
+    for fn, _, k in plan.ops:       # flags and buffers go together
+        if getattr(fn, "__name__", "") == "igemm":
+            assert bool(k["flags"] & L.EPI_LNSTAT) == (k.get("ln_stats_out") is not None)
+            assert k.get("ln_stats_in") is None or (k["flags"] & L.EPI_LNFOLD)
+    monkeypatch.setattr(E, "LN_STATS_FROM_PRODUCER", False)     # switch off: LayerNorm launches are back
+    plan2 = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    assert sum(1 for fn, _, _ in plan2.ops if getattr(fn, "__name__", "") == "layernorm") == 48
+
+
 def test_unet_plan_baseline_mode(full_sd):
     torch.manual_seed(2)
     sd = full_sd

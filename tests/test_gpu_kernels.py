@@ -163,6 +163,70 @@ def test_igemm_layernorm_fold(hip, tile_m, tile_n, tune, geglu):
                       partial=hip.zeros((2 * m * n,), F32), ln_c1=dev(hip, c1.contiguous()))
 
 
+@pytest.mark.parametrize("ptile,ptune", [((64, 64), 0), ((64, 160), 0), ((128, 160), 0), ((128, 128), 0), ((64, 160), 32),
+                                         ((128, 128), 32)])
+@pytest.mark.parametrize("ctile,ctune,geglu", [((128, 160), 64, False), ((128, 160), 32, False), ((128, 128), 32, True),
+                                               ((128, 128), 64, True), ((64, 64), 0, False)])
+def test_igemm_layernorm_statistics_from_producer(hip, ptile, ptune, ctile, ctune, geglu):
+    """DADD_EPI_LNSTAT -> ln_stats_in: the producing linear (bias + residual epilogue) writes the row partials of its
+    rounded output, [N / (tile_n/2)][M][2]; the consumer folds LayerNorm with them on ANY kernel (LDS-DMA, persistent
+    ring, register-staged = tune 32).  Checks: partials == sums over the stored fp16 output (fp32 order: 1e-5 rel.),
+    consumer == LayerNorm -> Linear (-> GEGLU) of the producer's output in fp32 torch, run-to-run bit identity, and the
+    contract errors (wrong part count, GEGLU producer)."""
+    from progressive_stable_diffusion_amd import engine as E
+    from progressive_stable_diffusion_amd import lib as L
+    import torch.nn.functional as Fn
+    m, k0, c = 4096 + 64, 320, 640                 # ragged last row tile for the 128-row kernels
+    n = 1024 if (geglu or ctile[1] != 160) else 960
+    g = torch.Generator().manual_seed(81)
+    x0 = torch.randn(1, m, 1, k0, generator=g).to(F16)
+    w0 = (torch.randn(c, k0, generator=g) / math.sqrt(k0)).to(F16)
+    res = (torch.randn(1, m, 1, c, generator=g) + 2.0 * torch.randn(1, m, 1, 1, generator=g)).to(F16)
+    b0 = torch.randn(c, generator=g) * 0.1
+    parts = c // (ptile[1] // 2)
+    st = hip.zeros((parts, m, 2), F32)
+    h = hip.zeros((1, m, 1, c), F16)
+    pf = L.EPI_BIAS | L.EPI_RESIDUAL | L.EPI_LNSTAT | ptune
+    hip.igemm(dev(hip, x0), dev(hip, w0), h, bias=dev(hip, b0), residual=dev(hip, res), flags=pf, tile_m=ptile[0],
+              tile_n=ptile[1], ln_stats_out=st)
+    hip.synchronize()
+    hc = h.float().cpu().reshape(m, parts, -1)
+    want = torch.stack([hc.sum(-1), (hc * hc).sum(-1)], dim=-1).permute(1, 0, 2)
+    err = (st.cpu() - want).abs().max().item()
+    assert err <= 1e-5 * want.abs().max().item() + 1e-4, (err, ptile, ptune)
+    # consumer
+    w = torch.randn(n, c, generator=g) / math.sqrt(c)
+    b = torch.randn(n, generator=g) * 0.1
+    gamma, beta = 1.0 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    ref = Fn.linear(Fn.layer_norm(h.float().cpu(), (c,), gamma, beta, 1e-5), w.to(F16).float(), b)
+    if geglu:
+        hid, gate = ref.chunk(2, dim=-1)
+        ref = hid * Fn.gelu(gate)
+    w16, c1, bias = E.fold_layernorm(w, b, gamma, beta)
+    if geglu:
+        idx = E.geglu_interleave(torch.arange(n)[:, None].float(), torch.zeros(n))[0][:, 0].long()
+        w16, c1, bias = w16[idx], c1[idx], bias[idx]
+    cf = L.EPI_BIAS | L.EPI_LNFOLD | (L.EPI_GEGLU if geglu else 0) | ctune
+    wd, bd, cd = dev(hip, w16.contiguous()), dev(hip, bias.contiguous()), dev(hip, c1.contiguous())
+    o = hip.zeros((1, m, 1, n // 2 if geglu else n), F16)
+    hip.igemm(h, wd, o, bias=bd, flags=cf, tile_m=ctile[0], tile_n=ctile[1], ln_c1=cd, ln_stats_in=st)
+    hip.synchronize()
+    close(o, ref, 6e-3, 6e-3, f"ln stats {ptile}/{ptune} -> {ctile}/{ctune} geglu{geglu}")
+    o2 = hip.zeros(tuple(o.shape), F16)
+    for _ in range(2):
+        hip.igemm(h, wd, o2, bias=bd, flags=cf, tile_m=ctile[0], tile_n=ctile[1], ln_c1=cd, ln_stats_in=st)
+        hip.synchronize()
+        assert torch.equal(o2, o)
+    with pytest.raises(ValueError):           # the part count must be N / (tile_n / 2) of the launch that writes them
+        hip.igemm(dev(hip, x0), dev(hip, w0), h, flags=L.EPI_LNSTAT | ptune, tile_m=ptile[0], tile_n=ptile[1],
+                  ln_stats_out=hip.zeros((parts + 1, m, 2), F32))
+    if ptile[1] == 128:
+        with pytest.raises(ValueError):       # no row partials of a GEGLU output
+            hip.igemm(dev(hip, x0), dev(hip, rnd((1024, k0), 5)), hip.zeros((1, m, 1, 512), F16),
+                      flags=L.EPI_LNSTAT | L.EPI_GEGLU | ptune, tile_m=ptile[0], tile_n=128,
+                      ln_stats_out=hip.zeros((16, m, 2), F32))
+
+
 @pytest.mark.parametrize("taps", [1, 9])
 def test_igemm_skip_concat(hip, taps):
     b, h, c1, c2, n = 2, 8, 640, 320, 640
@@ -381,6 +445,15 @@ def test_attn2_fused(hip, b, hw, c):
     hip.attn2_fused(dev(hip, x), dev(hip, mcat), dev(hip, vw), dev(hip, bias), dev(hip, res), o)
     hip.synchronize()
     close(o, o_ref, 4e-3, 3e-3, f"attn2_fused {b}x{hw}x{c}")
+    # the LayerNorm row partials of the output (for the GEGLU projection behind norm3): same result, sums of what is stored
+    st = hip.zeros((c // 80, b * hw, 2), F32)
+    o_st = hip.zeros((b, hw, c), F16)
+    hip.attn2_fused(dev(hip, x), dev(hip, mcat), dev(hip, vw), dev(hip, bias), dev(hip, res), o_st, ln_stats_out=st)
+    hip.synchronize()
+    assert torch.equal(o_st, o)
+    oc = o.float().cpu().reshape(b * hw, c // 80, 80)
+    want = torch.stack([oc.sum(-1), (oc * oc).sum(-1)], dim=-1).permute(1, 0, 2)
+    assert (st.cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-4
     with pytest.raises(ValueError):
         hip.attn2_fused(dev(hip, x[:, :64]), dev(hip, mcat), dev(hip, vw), None, dev(hip, res[:, :64]),
                         hip.zeros((b, 64, c), F16))          # fewer than 128 tokens per sample

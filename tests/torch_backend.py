@@ -105,7 +105,7 @@ class TorchRefBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5, gn_ws=None, gn_nchunk=0):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None):
         self.launches += 1
         xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
         b, hi, wi, cin = xin.shape
@@ -126,8 +126,12 @@ class TorchRefBackend:
         assert y.shape[2] == ho and y.shape[3] == wo, (y.shape, out.shape)
         y = y.permute(0, 2, 3, 1)
         if flags & 128:                 # EPI_LNFOLD: rstd * (x (gamma o W)^T - mu * c1), statistics of the fp16 rows
-            mu = xin.mean(dim=-1, keepdim=True)
-            var = (xin * xin).mean(dim=-1, keepdim=True) - mu * mu
+            if ln_stats_in is not None:     # row partials [P][M][2] written by the producer of x (EPI_LNSTAT)
+                st = ln_stats_in.sum(dim=0).reshape(b, hi, wi, 2) / cin
+                mu, var = st[..., 0:1], st[..., 1:2] - st[..., 0:1] ** 2
+            else:
+                mu = xin.mean(dim=-1, keepdim=True)
+                var = (xin * xin).mean(dim=-1, keepdim=True) - mu * mu
             y = torch.rsqrt(var.clamp_min(0.0) + ln_eps) * (y - mu * ln_c1.float())
         act = flags & (256 | 512 | 1024)
         flags &= 15                     # tuning bits (16, 32) do not change the math
@@ -148,6 +152,9 @@ class TorchRefBackend:
         if flags & EPI_RESIDUAL:
             y = y + residual.float()
         out.copy_(y.to(out.dtype))
+        if ln_stats_out is not None:    # EPI_LNSTAT: row partials of the rounded output over blocks of N / P columns
+            o = out.float().reshape(b * ho * wo, ln_stats_out.shape[0], -1)
+            ln_stats_out.copy_(torch.stack([o.sum(dim=-1), (o * o).sum(dim=-1)], dim=-1).permute(1, 0, 2))
         if gn_ws is not None:           # EPI_GNSTAT: chunk partials of the rounded output, [B][nchunk][32][2]
             o = out.float().reshape(b, gn_nchunk, -1, 32, n // 32)
             part = torch.stack([o.sum(dim=(2, 4)), (o * o).sum(dim=(2, 4))], dim=-1)
@@ -181,7 +188,7 @@ class TorchRefBackend:
         p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
         out.copy_((p @ v).transpose(1, 2).reshape(b, n, c).to(out.dtype))
 
-    def attn2_fused(self, x, mcat, vw, bias, residual, out):
+    def attn2_fused(self, x, mcat, vw, bias, residual, out, ln_stats_out=None):
         b, hw, c = x.shape
         s = torch.einsum("bmc,bkc->bmk", x.float(), mcat.float())            # log2(e)/sqrt(d) folded in
         pr = torch.softmax(s.view(b, hw, 24, 16) * math.log(2.0), dim=-1).view(b, hw, 384)
@@ -190,6 +197,9 @@ class TorchRefBackend:
         if bias is not None:
             y = y + bias.float()
         out.copy_((y + residual.float()).to(out.dtype))
+        if ln_stats_out is not None:
+            o = out.float().reshape(b * hw, ln_stats_out.shape[0], -1)
+            ln_stats_out.copy_(torch.stack([o.sum(dim=-1), (o * o).sum(dim=-1)], dim=-1).permute(1, 0, 2))
 
     def tri_xattn(self, q, kv, out, gates, lam, mode, heads, lam_dev=None):
         if lam_dev is not None:
