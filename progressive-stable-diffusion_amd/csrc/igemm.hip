@@ -388,7 +388,9 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                "igemm: an activation epilogue excludes GEGLU and split-K");
   DADD_REQUIRE(!(a.flags & DADD_EPI_LNFOLD) || (a.ln_c1 && a.taps == 1 && a.C2 == 0 && d->splitk <= 1 && a.ln_eps > 0.f),
                "igemm: a folded LayerNorm needs c1, a plain linear over one source (K = C) and no split-K");
-  DADD_REQUIRE(a.ln_stats_in == nullptr || a.ln_parts_in > 0, "igemm: ln_stats_in needs ln_parts_in > 0");
+  DADD_REQUIRE(a.ln_stats_in == nullptr ||
+                   (a.ln_parts_in > 0 && (size_t)a.ln_parts_in * a.B * a.Ho * a.Wo * 8 < 0x7FF00000ull),
+               "igemm: ln_stats_in needs ln_parts_in > 0 and fewer than 2 GiB of partials");
   DADD_REQUIRE(a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ld_rowvec % 4 == 0,
                "igemm: leading dimensions must be multiples of 4");
 

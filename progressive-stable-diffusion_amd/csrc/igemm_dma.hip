@@ -39,12 +39,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Tile BM x BN x 64 with BM in {64, 128}, BN in {64, 128, 160}.  The 64-row tiles exist for the short GEMMs of the
 // 16x16 / 8x8 levels (M = 1024 / 256): they fill the chip without split-K slabs, and two of their workgroups
 // (64 KB of LDS each at 64x64) share a CU, so one's prologue / epilogue hides under the other's K loop.
-// LNF: a LayerNorm folded into this linear (igemm_args.h) — the MFMA waves also accumulate the row statistics.
-template <int BM, int BN, bool UPS, bool PERS, bool LNF>
+// LNK: how a LayerNorm folded into this linear (igemm_args.h) gets its row statistics.  0: no fold (or, on 64-row tiles,
+// the epilogue reads the producer's partials from global memory); 1: the MFMA waves accumulate them from the A
+// fragments; 2 (128-row tiles): the producer's partials, c1 and the composed bias are staged in LDS by the loader
+// waves (ln_lds.h).  Separate instantiations: the plain kernels carry none of the staging code (it cost the
+// persistent qkv / GEGLU launches 3-4 us in scalar spills when it was a run-time branch).
+template <int BM, int BN, bool UPS, bool PERS, int LNK>
 __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type exists only in device code; the host
                                       // pass needs just the launch stub of this signature
   constexpr bool WS = true;
+  constexpr bool LNF = LNK == 1;
   constexpr int WM = BM / 2, MI = WM / 16;   // compute waves: 2 (M) x 2 (N); rows / 16-row fragments per wave
   constexpr int WN = BN / 2;
   constexpr int J = WN / 16;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(512, (BM + BN) <= 128 ? 4 : 2) void igemm_dma_kerne
   // iteration later they are as old as the K tile issued with them and the plain wait covers both.  nk >= 3, so the
   // barrier that publishes them precedes the tile's epilogue.
   char* const ln_scr = smem + 4 * STAGE;
-  const bool ln_stage = !LNF && !UPS && ln_lds_usable(p, BM, nk);
+  const bool ln_stage = LNK == 2 && !UPS && ln_lds_usable(p, BM, nk);
   const bool ln_sts = ln_stage && ln_lds_stats(p, LN_LDS_BYTES);
   if (loader) {
     const int ln_extra = ln_stage ? ln_lds_count(p, wave, ln_sts) : 0;      // extras this wave issues per output tile
@@ -397,35 +402,45 @@ constexpr int smem_bytes() {   // ring + the epilogue's scratch (GroupNorm parti
   return 4 * (BM + BN) * BK * 2 + (BM == 128 ? LN_LDS_BYTES : 4096);
 }
 
-template <int BM, int BN, bool UPS, bool PERS, bool LNF>
+template <int BM, int BN, bool UPS, bool PERS, int LNK>
 int set_attr() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, UPS, PERS, LNF>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<BM, BN, UPS, PERS, LNK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes<BM, BN>()));
   return DADD_OK;
 }
 
 int g_num_cu = 0;
 
-template <int BM, int BN, bool UPS, bool PERS, bool LNF>
+template <int BM, int BN, bool UPS, bool PERS, int LNK>
 void launch1(const char* name, const IgemmArgs& a, dim3 grid, hipStream_t s) {
-  dadd_launch({name, dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_dma_kernel<BM, BN, UPS, PERS, LNF>, grid, dim3(512),
+  dadd_launch({name, dadd_igemm_flop(a), dadd_igemm_bytes(a)}, igemm_dma_kernel<BM, BN, UPS, PERS, LNK>, grid, dim3(512),
               smem_bytes<BM, BN>(), s, a);
 }
-// plain linears / convs and (no upsample) their LayerNorm-folded twins
+// plain linears / convs and (no upsample) their LayerNorm-folded twins; `names`: kernel name per LNK (profiling records)
 template <int BM, int BN, bool UPS, bool PERS>
-void launch(const char* name, const char* name_ln, const IgemmArgs& a, dim3 grid, hipStream_t s) {
+void launch(const char* const (&names)[3], const IgemmArgs& a, dim3 grid, hipStream_t s) {
   if constexpr (!UPS) {
     if ((a.flags & DADD_EPI_LNFOLD) && a.ln_stats_in == nullptr) {     // the kernel sums the rows itself
-      launch1<BM, BN, false, PERS, true>(name_ln, a, grid, s);
+      launch1<BM, BN, false, PERS, 1>(names[1], a, grid, s);
       return;
     }
+    if constexpr (BM == 128) {
+      if (a.flags & DADD_EPI_LNFOLD) {                                   // the producer's partials, staged in LDS
+        launch1<BM, BN, false, PERS, 2>(names[2], a, grid, s);
+        return;
+      }
+    }
   }
-  launch1<BM, BN, UPS, PERS, false>(name, a, grid, s);
+  launch1<BM, BN, UPS, PERS, 0>(names[0], a, grid, s);
 }
 template <int BM, int BN, bool PERS>
 int set_attr2() {
-  int rc = set_attr<BM, BN, false, PERS, false>();
-  return rc == DADD_OK ? set_attr<BM, BN, false, PERS, true>() : rc;
+  int rc = set_attr<BM, BN, false, PERS, 0>();
+  if (rc == DADD_OK) rc = set_attr<BM, BN, false, PERS, 1>();
+  if constexpr (BM == 128) {
+    if (rc == DADD_OK) rc = set_attr<BM, BN, false, PERS, 2>();
+  }
+  return rc;
 }
 
 }  // namespace
@@ -435,8 +450,8 @@ int dadd_init_igemm_dma() {
   if (rc == DADD_OK) rc = set_attr2<128, 160, true>();
   if (rc == DADD_OK) rc = set_attr2<128, 128, false>();
   if (rc == DADD_OK) rc = set_attr2<128, 160, false>();
-  if (rc == DADD_OK) rc = set_attr<128, 128, true, false, false>();
-  if (rc == DADD_OK) rc = set_attr<128, 160, true, false, false>();
+  if (rc == DADD_OK) rc = set_attr<128, 128, true, false, 0>();
+  if (rc == DADD_OK) rc = set_attr<128, 160, true, false, 0>();
   if (rc == DADD_OK) rc = set_attr2<64, 64, false>();
   if (rc == DADD_OK) rc = set_attr2<64, 128, false>();
   if (rc == DADD_OK) rc = set_attr2<64, 160, false>();
@@ -460,23 +475,23 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_m, int tile_n, int nsplit
                "igemm(dma): operand larger than the 2 GiB buffer window");
   if (tile_m == 128 && dadd_igemm_dma_persistent(a, nsplit)) {
     dim3 grid(g_num_cu);
-    if (tile_n == 160) launch<128, 160, false, true>("igemm_dma_kernel<128, 160, false, true, false>", "igemm_dma_kernel<128, 160, false, true, true>", a, grid, s);
-    else launch<128, 128, false, true>("igemm_dma_kernel<128, 128, false, true, false>", "igemm_dma_kernel<128, 128, false, true, true>", a, grid, s);
+    if (tile_n == 160) { static const char* const nm[3] = {"igemm_dma_kernel<128, 160, false, true, 0>", "igemm_dma_kernel<128, 160, false, true, 1>", "igemm_dma_kernel<128, 160, false, true, 2>"}; launch<128, 160, false, true>(nm, a, grid, s); }
+    else { static const char* const nm[3] = {"igemm_dma_kernel<128, 128, false, true, 0>", "igemm_dma_kernel<128, 128, false, true, 1>", "igemm_dma_kernel<128, 128, false, true, 2>"}; launch<128, 128, false, true>(nm, a, grid, s); }
     DADD_LAUNCH_CHECK();
     return DADD_OK;
   }
   dim3 grid(total, nsplit);
   if (tile_m == 64) {
     DADD_REQUIRE(!a.ups, "igemm(dma): the 64-row tiles have no upsample gather");
-    if (tile_n == 160) launch<64, 160, false, false>("igemm_dma_kernel<64, 160, false, false, false>", "igemm_dma_kernel<64, 160, false, false, true>", a, grid, s);
-    else if (tile_n == 128) launch<64, 128, false, false>("igemm_dma_kernel<64, 128, false, false, false>", "igemm_dma_kernel<64, 128, false, false, true>", a, grid, s);
-    else launch<64, 64, false, false>("igemm_dma_kernel<64, 64, false, false, false>", "igemm_dma_kernel<64, 64, false, false, true>", a, grid, s);
+    if (tile_n == 160) { static const char* const nm[3] = {"igemm_dma_kernel<64, 160, false, false, 0>", "igemm_dma_kernel<64, 160, false, false, 1>", "igemm_dma_kernel<64, 160, false, false, 2>"}; launch<64, 160, false, false>(nm, a, grid, s); }
+    else if (tile_n == 128) { static const char* const nm[3] = {"igemm_dma_kernel<64, 128, false, false, 0>", "igemm_dma_kernel<64, 128, false, false, 1>", "igemm_dma_kernel<64, 128, false, false, 2>"}; launch<64, 128, false, false>(nm, a, grid, s); }
+    else { static const char* const nm[3] = {"igemm_dma_kernel<64, 64, false, false, 0>", "igemm_dma_kernel<64, 64, false, false, 1>", "igemm_dma_kernel<64, 64, false, false, 2>"}; launch<64, 64, false, false>(nm, a, grid, s); }
   } else if (tile_n == 160) {
-    if (a.ups) launch<128, 160, true, false>("igemm_dma_kernel<128, 160, true, false, false>", "", a, grid, s);
-    else launch<128, 160, false, false>("igemm_dma_kernel<128, 160, false, false, false>", "igemm_dma_kernel<128, 160, false, false, true>", a, grid, s);
+    if (a.ups) { static const char* const nm[3] = {"igemm_dma_kernel<128, 160, true, false, 0>", "igemm_dma_kernel<128, 160, true, false, 1>", "igemm_dma_kernel<128, 160, true, false, 2>"}; launch<128, 160, true, false>(nm, a, grid, s); }
+    else { static const char* const nm[3] = {"igemm_dma_kernel<128, 160, false, false, 0>", "igemm_dma_kernel<128, 160, false, false, 1>", "igemm_dma_kernel<128, 160, false, false, 2>"}; launch<128, 160, false, false>(nm, a, grid, s); }
   } else {
-    if (a.ups) launch<128, 128, true, false>("igemm_dma_kernel<128, 128, true, false, false>", "", a, grid, s);
-    else launch<128, 128, false, false>("igemm_dma_kernel<128, 128, false, false, false>", "igemm_dma_kernel<128, 128, false, false, true>", a, grid, s);
+    if (a.ups) { static const char* const nm[3] = {"igemm_dma_kernel<128, 128, true, false, 0>", "igemm_dma_kernel<128, 128, true, false, 1>", "igemm_dma_kernel<128, 128, true, false, 2>"}; launch<128, 128, true, false>(nm, a, grid, s); }
+    else { static const char* const nm[3] = {"igemm_dma_kernel<128, 128, false, false, 0>", "igemm_dma_kernel<128, 128, false, false, 1>", "igemm_dma_kernel<128, 128, false, false, 2>"}; launch<128, 128, false, false>(nm, a, grid, s); }
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

@@ -44,10 +44,12 @@ __device__ __forceinline__ void ln_lds_issue(const IgemmArgs& p, char* scr, int 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (ln_lptr_t)(scr + 1024), 16, cv, 0, 0, 0);
   }
   if (!stats) return;
-  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.ln_stats_in, 0, (int)((size_t)p.ln_parts_in * p.M * 8), 0x00020000);
+  // (32-bit scalar arithmetic only: a 64-bit product runs on the VALU, the descriptor then lives in VGPRs and every DMA
+  // instruction sits in a waterfall loop — tests/test_isa_guards.py; the host checks parts * M * 8 < 2^31)
+  const __amdgpu_buffer_rsrc_t rsS =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_stats_in, 0, p.ln_parts_in * p.M * 8, 0x00020000);
   for (int pp = w; pp < p.ln_parts_in; pp += 4)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (ln_lptr_t)(scr + LN_LDS_STATS + pp * 1024), 16,
-                                             (unsigned)(((size_t)pp * p.M + m0) * 8 + lane * 16), 0, 0, 0);
+                                             (unsigned)(lane * 16), (pp * p.M + m0) * 8, 0, 0);
 }
 #endif

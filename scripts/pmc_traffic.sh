@@ -2,7 +2,7 @@
 # HBM traffic of the dominant kernel, per MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE in SEPARATE
 # rocprofv3 --pmc passes (no trace domains), KB units, FETCH_SIZE doubled on gfx950.
 set -u
-tag=${1:-traffic}; export DOM="${2:-igemm_dma_kernel<128, 160, false, false, false>}"; out=gpurun_out/$tag; mkdir -p "$out"; export TMPDIR=/tmp
+tag=${1:-traffic}; export DOM="${2:-igemm_dma_kernel<128, 160, false, false, 0>}"; out=gpurun_out/$tag; mkdir -p "$out"; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d "$out/$c" -- python scripts/step_pmc.py > "$out/$c.log" 2>&1

@@ -49,8 +49,10 @@ def test_dma_loads_are_not_in_waterfall_loops(asm):
     for name, body in funcs.items():
         dma = [i for i, l in enumerate(body) if "buffer_load_dwordx4" in l and " lds" in l]
         assert dma, name
-        for i in dma:
-            assert not any("s_cbranch_execnz" in l for l in body[i + 1:i + 4]), (name, body[i - 6:i + 4])
+        for i in dma:       # a waterfall loop: v_readfirstlane of the divergent operand before, exec-loop branch behind
+            looped = any("s_cbranch_execnz" in l for l in body[i + 1:i + 4])
+            picked = any("v_readfirstlane" in l for l in body[max(0, i - 10):i])
+            assert not (looped and picked), (name, body[i - 10:i + 4])
 
 
 def test_no_scratch_and_two_waves_per_simd(asm):
