@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--tiny-clip", action="store_true", help="2-layer CLIP tower (debug only)")
+    p.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                   help="A/B hook: override an engine policy variable (e.g. LN_STATS_FROM_PRODUCER=False); echoed in config")
     return p.parse_args()
 
 
@@ -180,6 +182,14 @@ def main():
     torch.cuda.set_device(dev)
 
     from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    if a.set:
+        import ast
+        from progressive_stable_diffusion_amd import engine as E
+        for kv in a.set:
+            k, v = kv.split("=", 1)
+            if not hasattr(E, k):
+                raise SystemExit(f"--set: engine has no policy variable {k}")
+            setattr(E, k, ast.literal_eval(v))
     from progressive_stable_diffusion_amd import lib
     from progressive_stable_diffusion_amd import weights as W
     from progressive_stable_diffusion_amd.config import default_config
@@ -242,7 +252,8 @@ def main():
             "config": {"workload": f"{a.image_size}x{a.image_size}, {a.ddim_steps} DDIM steps, bs={a.batch}/GPU, "
                                    f"delta-steer lambda={a.steer_scale}, routing gates on, conditioning prep + "
                                    "VAE decode included", "global_batch": n_total,
-                       "parallelism": f"batch-shard x{world} + 1 all-gather of uint8 frames"},
+                       "parallelism": f"batch-shard x{world} + 1 all-gather of uint8 frames",
+                       **({"policy_overrides": a.set} if a.set else {})},
             "achieved_tflops_whole_job": value * FLOP_PER_IMAGE / 1e12 if a.image_size == 512 else None,
             "frac_of_mfma_peak_whole_job": (value * FLOP_PER_IMAGE / 1e12) / (PEAK_F16_TFLOPS * world)
             if a.image_size == 512 else None,

@@ -62,13 +62,24 @@ constexpr unsigned OOB = 0x80000000u;
 // WT = image width (64, 32, 16): compile-time so that the fragments of one image row share ONE address register
 // (they are 16 pixels = 2048 B apart and 16 = 0 mod 8 keeps the swizzle term) and the MFMA waves compute
 // 64 / WT addresses per tap instead of four.
-template <int WT>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
+//
+// DUO: TWO MFMA waves per SIMD (12 waves: 0-3 take K half 0 of every tap, 4-7 K half 1, 8-11 move data).  With one
+// MFMA wave per SIMD the matrix pipe idles whenever that wave waits for a fragment read (measured with s_memtime
+// stamps: 1390 cycles per tap for 640 cycles of MFMA); the two waves of a SIMD hold partial sums over disjoint halves
+// of K, read the same number of fragments in total (no extra LDS traffic) and fill each other's stalls.  Fragments
+// are single-buffered: a register is reloaded for the next tap right behind the MFMA that used it last.  After the
+// last tap waves 4-7 park their accumulators in LDS, waves 0-3 add them and run the epilogue.
+// MEASURED (profiles/r02_zn_halo_duo_ab.txt, same box, one UNet step): 42.1 / 36.4 / 35.9 us against 40.5 / 35.5 / 36.1 us
+// for the one-wave build at W = 64 / 32 / 16 — no gain: the tap time is set by the LDS-DMA stream (three weight tiles
+// = 60 KB in flight per CU at ~1.5 us of loaded latency), not by stalls of the MFMA waves.  Kept as the A/B build
+// (DADD_TUNE_SHALLOW on a 3x3 / stride-1 conv), not the default.
+template <int WT, bool DUO>
+__global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool loader = wave_all >= 4;
+  const bool loader = wave_all >= (DUO ? 8 : 4);
   const int wave = wave_all & 3;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -247,6 +258,72 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
     }
   };
 
+  if constexpr (DUO) {
+    const int hx = (wave_all >> 2) * 64;            // K half of this wave, as the XOR term of its fragment addresses
+    const int fbh = fb0 ^ hx;
+    __builtin_amdgcn_s_barrier();                   // halo of the first chunk and weight tiles 0..2 landed
+    __builtin_amdgcn_sched_barrier(0);
+    h8 xa[4], wb[J];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      xa[i] = *reinterpret_cast<const h8*>(smem + W_RING + (addr_of(std::integral_constant<int, 0>{}, i / FPL) ^ hx) + (i % FPL) * 2048);
+#pragma unroll
+    for (int j = 0; j < J; ++j) wb[j] = *reinterpret_cast<const h8*>(smem + fbh + j * 2048);
+    int gi = 0;
+    const char* hb = smem + W_RING;                 // halo buffer of the current chunk
+    const char* hbo = smem + W_RING + HALO_BYTES;   // ... of the next chunk
+    auto tap2 = [&](auto TP) {
+      constexpr int T = decltype(TP)::value, NT = (T + 1) % 9;
+      __builtin_amdgcn_s_barrier();                 // one barrier per tap on all twelve waves
+      __builtin_amdgcn_sched_barrier(0);
+      const char* wnext = smem + ((gi + 1) & 3) * B_BYTES + fbh;
+      const char* hbn = T == 8 ? hbo : hb;          // tap (0, 0) of the next chunk reads the other buffer
+#pragma unroll
+      for (int k = 0; k < 4 * J; ++k) {
+        const int jj = k / 4, ii = k % 4;
+        acc[jj][ii] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[jj], xa[ii], acc[jj][ii], 0, 0, 0);
+        if (ii == 3) wb[jj] = *reinterpret_cast<const h8*>(wnext + jj * 2048);       // last use of wb[jj] this tap
+        if (jj == J - 1)                                                             // last use of xa[ii] this tap
+          xa[ii] = *reinterpret_cast<const h8*>(hbn + (addr_of(std::integral_constant<int, NT>{}, ii / FPL) ^ hx) + (ii % FPL) * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ++gi;
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int c = c0; c < c1; ++c) {
+      tap2(std::integral_constant<int, 0>{});
+      tap2(std::integral_constant<int, 1>{});
+      tap2(std::integral_constant<int, 2>{});
+      tap2(std::integral_constant<int, 3>{});
+      tap2(std::integral_constant<int, 4>{});
+      tap2(std::integral_constant<int, 5>{});
+      tap2(std::integral_constant<int, 6>{});
+      tap2(std::integral_constant<int, 7>{});
+      tap2(std::integral_constant<int, 8>{});
+      const char* sw = hb;
+      hb = hbo;
+      hbo = sw;
+    }
+    // ---- add the two K halves.  First barrier: every loader wave has terminated, i.e. all its DMA — the zero fills of
+    // the dead tiles past the end included — has landed and the weight ring can be overwritten; the waves of half 1 park
+    // their accumulators there ([register][lane] f4: conflict free), second barrier, the waves of half 0 add them.
+    __builtin_amdgcn_s_barrier();
+    f4* park = reinterpret_cast<f4*>(smem + wave * (J * 4 * 64 * 16));
+    if (wave_all >= 4) {
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) park[(j * 4 + i) * 64 + lane] = acc[j][i];
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wave_all >= 4) return;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] += park[(j * 4 + i) * 64 + lane];
+    igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + GN_OFF);
+    return;
+  }
   __builtin_amdgcn_s_barrier();                     // halo of the first chunk and weight tiles 0..2 landed
   __builtin_amdgcn_sched_barrier(0);
   h8 xa0[4], xa1[4], wb0[J], wb1[J];
@@ -319,16 +396,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const IgemmArgs p)
 #endif
 }
 
+template <int WT, bool DUO>
+int set_attr_halo() {
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WT, DUO>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  return DADD_OK;
+}
+
 }  // namespace
 
 int dadd_init_conv_halo() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<64>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<32>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<16>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-  return DADD_OK;
+  int rc = set_attr_halo<64, false>();
+  if (rc == DADD_OK) rc = set_attr_halo<32, false>();
+  if (rc == DADD_OK) rc = set_attr_halo<16, false>();
+  if (rc == DADD_OK) rc = set_attr_halo<64, true>();
+  if (rc == DADD_OK) rc = set_attr_halo<32, true>();
+  if (rc == DADD_OK) rc = set_attr_halo<16, true>();
+  return rc;
 }
 
 // Shapes this kernel takes (everything else stays on the implicit GEMM).
@@ -346,9 +430,16 @@ int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
                "conv_halo: operand larger than the 2 GiB buffer window");
   dim3 grid(a.mtiles * a.ntiles, nsplit);
   const double flop = dadd_igemm_flop(a), bytes = dadd_igemm_bytes(a);
-  if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64>", flop, bytes}, conv3x3_halo_kernel<64>, grid, dim3(512), SMEM_BYTES, s, a);
-  else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32>", flop, bytes}, conv3x3_halo_kernel<32>, grid, dim3(512), SMEM_BYTES, s, a);
-  else dadd_launch({"conv3x3_halo_kernel<16>", flop, bytes}, conv3x3_halo_kernel<16>, grid, dim3(512), SMEM_BYTES, s, a);
+  const bool duo = (a.flags & DADD_TUNE_SHALLOW) != 0;   // A/B switch: measured equal to the one-wave build (see the kernel comment)
+  if (duo) {
+    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, true>", flop, bytes}, conv3x3_halo_kernel<64, true>, grid, dim3(768), SMEM_BYTES, s, a);
+    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, true>", flop, bytes}, conv3x3_halo_kernel<32, true>, grid, dim3(768), SMEM_BYTES, s, a);
+    else dadd_launch({"conv3x3_halo_kernel<16, true>", flop, bytes}, conv3x3_halo_kernel<16, true>, grid, dim3(768), SMEM_BYTES, s, a);
+  } else {
+    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, false>", flop, bytes}, conv3x3_halo_kernel<64, false>, grid, dim3(512), SMEM_BYTES, s, a);
+    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, false>", flop, bytes}, conv3x3_halo_kernel<32, false>, grid, dim3(512), SMEM_BYTES, s, a);
+    else dadd_launch({"conv3x3_halo_kernel<16, false>", flop, bytes}, conv3x3_halo_kernel<16, false>, grid, dim3(512), SMEM_BYTES, s, a);
+  }
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }

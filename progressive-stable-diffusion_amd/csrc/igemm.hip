@@ -487,8 +487,10 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                  "igemm: LayerNorm row partials need ln_stats_out, N %% (tile_n/2) == 0, ln_parts_out == N / (tile_n/2) = %d, "
                  "no GEGLU and no finish-kernel split-K", a.N / wn_cols);
   }
-  if (halo)
+  if (halo) {
+    if (d->flags & DADD_TUNE_SHALLOW) a.flags |= DADD_TUNE_SHALLOW;   // A/B: the two-MFMA-waves-per-SIMD build
     rc = dadd_launch_conv_halo(a, halo_ns, s);
+  }
   else if (dma)
     rc = dadd_launch_igemm_dma(a, tile_m, tile_n, nsplit, s);
   else if (tile_m == 128)

@@ -87,6 +87,10 @@ def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return w16, w16.double().sum(dim=1).float(), bias.float()
 
 
+# conv3x3_halo_kernel with two MFMA waves per SIMD (csrc/conv_halo.hip, DUO): measured equal to the one-wave build
+# (profiles/r02_zn_halo_duo_ab.txt), so off; True is the A/B switch
+HALO_DUO = False
+
 # GroupNorm statistics written by the producing GEMM's epilogue (no gn_stats launch, one read of the tensor less).
 GN_FROM_EPILOGUE = True
 GN_FUSED_MAX_BYTES = 16 * 1024       # csrc/norm.hip: below this slab size the single-launch LDS GroupNorm runs
@@ -270,6 +274,8 @@ class _Plan:
         m = out_shape[0] * out_shape[1] * out_shape[2]
         tile_m, tile_n, sk, tune = plan_tiling(m, n, w.shape[1], taps, bool(flags & L.EPI_GEGLU), residual is not None,
                                                ups, stride)
+        if taps == 9 and HALO_DUO:
+            tune |= L.TUNE_SHALLOW
         if ln_c1 is not None:
             sk = 1                      # the row statistics come from whole rows of A: no K slices
         partial = self.pool.get((sk * m * n,), F32) if sk > 1 else None

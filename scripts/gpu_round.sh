@@ -24,8 +24,15 @@ for s in $steps; do
     parity)  run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 ;;
     smoke)   run smoke 300 python __graft_entry__.py smoke ;;
     stepprof) TAILN=60 run stepprof 600 python scripts/step_profile.py --list --out "$out/step_profile.txt" ;;
-    stepprofab) TAILN=5 run stepprof_a 600 python scripts/step_profile.py --list --out "$out/step_profile_a.txt" --set LN_STATS_FROM_PRODUCER=False
-                TAILN=5 run stepprof_b 600 python scripts/step_profile.py --list --out "$out/step_profile_b.txt" ;;
+    stepprofab) # same-box A/B of one UNet step: SET_A / SET_B = engine policy overrides (NAME=VALUE), e.g. SET_A=HALO_DUO=False
+                TAILN=5 run stepprof_a 600 python scripts/step_profile.py --list --out "$out/step_profile_a.txt" ${SET_A:+--set $SET_A}
+                TAILN=5 run stepprof_b 600 python scripts/step_profile.py --list --out "$out/step_profile_b.txt" ${SET_B:+--set $SET_B} ;;
+    benchab) # same-box A/B of the whole pass: BENCH_A / BENCH_B = extra bench.py arguments (e.g. "--set LN_STATS_FROM_PRODUCER=False")
+             TAILN=2 run bench_a 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_A:-}
+             TAILN=2 run bench_b 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_B:-}
+             TAILN=2 run bench_a2 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_A:-}
+             TAILN=2 run bench_b2 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_B:-}
+             grep -h -o '"ms_per_step": [0-9.]*' "$out"/bench_a.log "$out"/bench_b.log "$out"/bench_a2.log "$out"/bench_b2.log ;;
     stepprofvae) TAILN=40 run stepprofvae 600 python scripts/step_profile.py --vae --list --out "$out/step_profile_vae.txt" ;;
     opbench) TAILN=80 run opbench 600 python scripts/op_bench.py "$tag" ;;
     opbenchvae) TAILN=60 run opbenchvae 600 python scripts/op_bench.py "$tag" --vae ;;

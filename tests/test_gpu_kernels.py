@@ -345,6 +345,13 @@ def test_conv3x3_halo_kernel(hip, b, h, c1, c2, n, splitk):
     kw["flags"] = 7 | 32
     o2, _ = run_igemm(hip, x, w, (b, h, h, n), **kw)
     close(o, o2, 2e-3, 2e-3, "halo conv vs register-staged implicit GEMM")
+    # the two-MFMA-waves-per-SIMD build (tune 16: K halves summed apart -> tolerance) and its run to run bit identity
+    kw["flags"] = 7 | 16
+    o1, _ = run_igemm(hip, x, w, (b, h, h, n), splitk=splitk, in_launch_combine=False, **kw)
+    close(o1, o_ref, 3e-3, 2e-3, "halo conv, two MFMA waves per SIMD")
+    close(o, o1, 2e-3, 2e-3, "halo conv: two MFMA waves per SIMD vs one")
+    o3, _ = run_igemm(hip, x, w, (b, h, h, n), splitk=splitk, in_launch_combine=False, **kw)
+    assert torch.equal(o3.cpu(), o1.cpu())
 
 
 def test_igemm_geglu(hip):
