@@ -206,8 +206,9 @@ int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, voi
  * MLP, src/models/ordinal_embedder.py:107-127).  act: 0 none, 1 SiLU, 2 GELU (exact). */
 int dadd_linear_rows_f32(const float* x, const void* w, const float* bias, float* out, int M, int K,
                          int N, int act_in, int act_out, int w_f32, void* stream);
-/* Per-step prologue run from inside the captured graph: row = *step;
- * cur_rows[b][:] = table[row][:] for b < B; cur_coef[0:4] = coef[row][0:4]; then *step += 1. */
+/* Per-step prologue run from inside the captured graph: row = step[0];
+ * cur_rows[b][:] = table[row][:] for b < B; cur_coef[0:4] = coef[row][0:4]; then step[0] += 1.
+ * step: TWO int32 (row, arrival ticket of the kernel's blocks — zero between launches). */
 int dadd_begin_step(const float* table, float* cur_rows, int B, int ncols, const float* coef,
                     float* cur_coef, int32_t* step, void* stream);
 /* DDIM update (eta = 0), op-for-op as inference_pipeline_ip.py:430-456:

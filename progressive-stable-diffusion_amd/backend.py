@@ -244,6 +244,7 @@ class HipBackend:
                                                 img.numel() // c, c, float(eps), self.s))
 
     def begin_step(self, table, cur_rows, coef, cur_coef, step):
+        assert step.numel() == 2 and step.dtype == torch.int32
         L.check(self.lib.dadd_begin_step(_p(table), _p(cur_rows), cur_rows.shape[0], table.shape[1],
                                          _p(coef), _p(cur_coef), _p(step), self.s))
 

@@ -848,7 +848,7 @@ class DdimLoop:
     def __init__(self, unet: UNetPlan, max_steps: int = 1000):
         self.u = unet
         self.be = unet.be
-        self.step = self.be.zeros((1,), torch.int32)
+        self.step = self.be.zeros((2,), torch.int32)       # row of the next step, block ticket of dadd_begin_step
         self.cur_coef = self.be.zeros((4,), F32)
         self.graphs: Dict[Tuple, object] = {}
         self.cap = 0

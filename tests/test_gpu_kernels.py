@@ -565,10 +565,10 @@ def test_ddim_update_is_bit_exact(hip):
 
 
 def test_begin_step_and_graph_replay(hip):
-    table, coef = rnd((6, 64), 48, 1.0, F32), rnd((6, 4), 49, 1.0, F32)
+    table, coef = rnd((6, 1000), 48, 1.0, F32), rnd((6, 4), 49, 1.0, F32)     # 1000 columns: four blocks, ragged
     td, cd = dev(hip, table), dev(hip, coef)
-    cur, cc = hip.zeros((3, 64), F32), hip.zeros((4,), F32)
-    step = hip.zeros((1,), torch.int32)
+    cur, cc = hip.zeros((3, 1000), F32), hip.zeros((4,), F32)
+    step = hip.zeros((2,), torch.int32)       # (row, block ticket)
     acc = hip.zeros((1, 4, 1, 1), F32)
     ones = dev(hip, torch.tensor([1.0, 0.0, 1.0, 1.0]))   # x <- clamp(x) + eps
     eps = dev(hip, torch.full((1, 4, 1, 1), 0.25))
@@ -579,7 +579,7 @@ def test_begin_step_and_graph_replay(hip):
     for i in range(5):
         hip.graph_launch(g)
         hip.synchronize()
-        assert int(step.item()) == i + 1
+        assert step.cpu().tolist() == [i + 1, 0]
         assert torch.equal(cur.cpu(), table[i][None].expand(3, -1))
         assert torch.equal(cc.cpu(), coef[i])
     assert torch.allclose(acc.cpu(), torch.full((1, 4, 1, 1), 1.25))

@@ -261,10 +261,10 @@ class TorchRefBackend:
         out.copy_(F.layer_norm(v, (v.shape[-1],), gamma.float(), beta.float(), eps).reshape(out.shape))
 
     def begin_step(self, table, cur_rows, coef, cur_coef, step):
-        r = int(step.item())
+        r = int(step[0].item())
         cur_rows.copy_(table[r][None, :].expand_as(cur_rows))
         cur_coef.copy_(coef[r])
-        step += 1
+        step[0] += 1
 
     def ddim_update(self, x, eps_c, eps_u, guidance, coef, guidance_dev=None):
         if guidance_dev is not None:
