@@ -113,8 +113,19 @@ int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
  * [-30, 20] (the logvar half of the VAE encoder moments, diffusers DiagonalGaussianDistribution). */
 int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* bias, void* out, int B, int H,
                           int W, int Cout, void* stream);
+/* conv_in of the UNet in one launch: fp32 NCHW latents (C <= 4 channels, rounded to fp16 in registers exactly as
+ * dadd_pack_nchw_f32_to_nhwc8_f16 with scale 1 does) -> fp16 NHWC Cout; w is the [Cout][9][8] layout of conv_cin8.
+ * Replaces UNet2DConditionModel.conv_in behind OrdinalUNet.forward (src/models/unet/unet.py:140-144). */
+int dadd_conv_in_nchw_f16(const float* x_nchw, const void* w, const float* bias, void* out, int B, int C,
+                          int H, int W, int Cout, void* stream);
 int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw, int B,
                            int H, int W, int C, int Cout, int mode, void* stream);
+/* conv_out of the UNet fused with the deterministic DDIM update of the sampler (no CFG): eps = conv3x3(x) + bias is
+ * never stored; latents (fp32 NCHW, B x Cout x H x W) are updated in place with coef = {sqrt(a_t), sqrt(1-a_t),
+ * sqrt(a_prev) (< 0: last step, return x0), sqrt(1-a_prev)} read from device memory — the arithmetic of
+ * dadd_ddim_update_f32, operation for operation (inference_pipeline_ip.py:434-456). */
+int dadd_conv_out_ddim_f16(const void* x, const void* w, const float* bias, float* latents, const float* coef,
+                           int B, int H, int W, int C, int Cout, void* stream);
 
 /* fp32 NCHW (C real channels, C<=8) -> fp16 NHWC with 8 channels (zero padded), times `scale`;
  * optional CxC matrix + bias applied per pixel first (AutoencoderKL.post_quant_conv 1x1).

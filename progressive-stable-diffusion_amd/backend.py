@@ -96,12 +96,26 @@ class HipBackend:
         L.check(self.lib.dadd_conv3x3_cin8_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, w.shape[0],
                                                self.s))
 
+    def conv_in_nchw(self, x, w, bias, out):
+        """fp32 NCHW latents (<= 4 channels) -> fp16 NHWC: pack_latents + conv_cin8 in one launch."""
+        b, c, h, wd = x.shape
+        assert x.dtype == torch.float32 and c <= 4 and w.shape[1:] == (9, 8) and out.shape == (b, h, wd, w.shape[0])
+        L.check(self.lib.dadd_conv_in_nchw_f16(_p(x), _p(w), _p(bias), _p(out), b, c, h, wd, w.shape[0], self.s))
+
     def conv_cout4(self, x, w, bias, out, mode=0):
         b, h, wd, c = x.shape
         co = w.shape[0]
         assert w.shape == (co, 9, c) and out.shape == (b, co, h, wd) and out.dtype == torch.float32
         L.check(self.lib.dadd_conv3x3_cout4_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, c, co,
                                                 int(mode), self.s))
+
+    def conv_out_ddim(self, x, w, bias, latents, coef):
+        """conv_out fused with the DDIM update: ``latents`` (fp32 NCHW) are stepped in place, eps is not stored."""
+        b, h, wd, c = x.shape
+        co = w.shape[0]
+        assert w.shape == (co, 9, c) and latents.shape == (b, co, h, wd) and latents.dtype == torch.float32 \
+            and coef.numel() == 4 and coef.dtype == torch.float32
+        L.check(self.lib.dadd_conv_out_ddim_f16(_p(x), _p(w), _p(bias), _p(latents), _p(coef), b, h, wd, c, co, self.s))
 
     def q_sample(self, x0, noise, t, alphas_cumprod, out):
         b = x0.shape[0]

@@ -69,6 +69,47 @@ __global__ __launch_bounds__(256) void conv_cin8_kernel(const half_t* __restrict
   *reinterpret_cast<h8*>(out + (size_t)pix * Cout + co0) = r;
 }
 
+// conv_in of the UNet straight from the fp32 NCHW latents (C <= 4 channels): the layout change + fp16 rounding of
+// pack_kernel happens in registers (same rounding point), two v_dot2_f32_f16 per tap and output channel instead of
+// 24 converts + multiply-adds over the zero-padded 8 channels.  thread = (pixel, group of 8 output channels); the
+// weights [Cout][9][8] (channels C.. zero) are wave-uniform.  Replaces pack_kernel + conv_cin8_kernel (4.3 + 28 us at
+// 4x64x64 -> 320 channels: the old kernel was VALU-bound).
+__global__ __launch_bounds__(256) void conv_in_nchw_kernel(const float* __restrict__ x, const half_t* __restrict__ w,
+                                                           const float* __restrict__ bias, half_t* __restrict__ out,
+                                                           int B, int C, int H, int W, int Cout) {
+  typedef _Float16 ci_h2 __attribute__((ext_vector_type(2)));
+  const int HW = H * W, npix = B * HW;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int co0 = blockIdx.y * 8;
+  if (pix >= npix) return;
+  const int b = pix / HW, rem = pix - b * HW, oy = rem / W, ox = rem - oy * W;
+  ci_h2 x01[9], x23[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float* xp = x + (size_t)b * C * HW + (ok ? iy * W + ix : rem);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (c < C && ok) ? xp[(size_t)c * HW] : 0.f;
+    x01[tap] = ci_h2{(_Float16)v[0], (_Float16)v[1]};
+    x23[tap] = ci_h2{(_Float16)v[2], (_Float16)v[3]};
+  }
+  h8 r;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float acc = bias ? bias[co0 + o] : 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const h4 wv = *reinterpret_cast<const h4*>(w + ((size_t)(co0 + o) * 9 + tap) * 8);
+      acc = __builtin_amdgcn_fdot2(x01[tap], ci_h2{wv[0], wv[1]}, acc, false);
+      acc = __builtin_amdgcn_fdot2(x23[tap], ci_h2{wv[2], wv[3]}, acc, false);
+    }
+    r[o] = (half_t)acc;
+  }
+  *reinterpret_cast<h8*>(out + (size_t)pix * Cout + co0) = r;
+}
+
 // conv3x3 pad1 to <=4 output channels, fp32 NCHW output.  16 lanes share a pixel (channel chunks of 8 strided over the
 // 16 lanes -> 256 contiguous bytes per tap) and every thread carries TWO pixels 16 apart, so one weight fragment read
 // from LDS serves both; the nine taps of a chunk are loaded back to back (18 independent 16-byte loads in flight per
@@ -80,7 +121,9 @@ __global__ __launch_bounds__(256) void conv_cout4_kernel(const half_t* __restric
                                                          const half_t* __restrict__ w,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ out, int B, int H, int W,
-                                                         int C, int Cout, int mode) {
+                                                         int C, int Cout, int mode,
+                                                         const float* __restrict__ coef) {
+#pragma clang fp contract(off)      // mode 3 is the DDIM update: individually rounded fp32 operations, as ddim_kernel
   extern __shared__ __attribute__((aligned(16))) char cc_smem[];
   half_t* ws = reinterpret_cast<half_t*>(cc_smem);          // [Cout][9][C]
   const int wtot = Cout * 9 * C;
@@ -154,7 +197,18 @@ __global__ __launch_bounds__(256) void conv_cout4_kernel(const half_t* __restric
       } else if (mode == 2) {
         v = fminf(fmaxf(v, -30.f), 20.f);    // DiagonalGaussianDistribution clamps logvar on construction
       }
-      out[((size_t)bb[q] * Cout + sub) * HW + (pixs[q] - bb[q] * HW)] = v;
+      float* dst = out + ((size_t)bb[q] * Cout + sub) * HW + (pixs[q] - bb[q] * HW);
+      if (mode == 3) {                       // v = eps of this latent element: the DDIM step in place (ddim_kernel, no CFG)
+        const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3];
+        const float sx = c1 * v;
+        const float num = *dst - sx;
+        float x0 = num / c0;
+        x0 = fminf(fmaxf(x0, -4.0f), 4.0f);
+        const float ta = c2 * x0;
+        const float tb = c3 * v;
+        v = (c2 < 0.f) ? x0 : ta + tb;
+      }
+      *dst = v;
     }
   }
 }
@@ -431,12 +485,25 @@ extern "C" int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* 
   return DADD_OK;
 }
 
-extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw,
-                                      int B, int H, int W, int C, int Cout, int mode, void* stream) {
+extern "C" int dadd_conv_in_nchw_f16(const float* x_nchw, const void* w, const float* bias, void* out, int B, int C,
+                                    int H, int W, int Cout, void* stream) {
+  DADD_REQUIRE(x_nchw && w && out, "conv_in_nchw: null pointer");
+  DADD_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4 && Cout > 0 && Cout % 8 == 0,
+               "conv_in_nchw: C must be 1..4 and Cout a multiple of 8");
+  DADD_REQUIRE(dadd_aligned16(w) && dadd_aligned16(out), "conv_in_nchw: w / out must be 16-byte aligned");
+  const int npix = B * H * W;
+  dadd_launch({"conv_in_nchw_kernel", 2.0 * npix * Cout * 9.0 * C, (double)npix * (4.0 * C + 2.0 * Cout)}, conv_in_nchw_kernel,
+              dim3((npix + 255) / 256, Cout / 8), dim3(256), 0, static_cast<hipStream_t>(stream), x_nchw,
+              static_cast<const half_t*>(w), bias, static_cast<half_t*>(out), B, C, H, W, Cout);
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}
+
+static int conv_cout4_launch(const void* x, const void* w, const float* bias, float* out_nchw, int B, int H, int W,
+                             int C, int Cout, int mode, const float* coef, void* stream) {
   DADD_REQUIRE(x && w && out_nchw, "conv_cout4: null pointer");
   DADD_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && Cout >= 1 && Cout <= 4,
                "conv_cout4: C must be x8 and Cout in 1..4");
-  DADD_REQUIRE(mode >= 0 && mode <= 2, "conv_cout4: mode must be 0, 1 or 2");
   DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(w), "conv_cout4: pointers must be 16-byte aligned");
   const int npix = B * H * W;
   const unsigned smem = (unsigned)(Cout * 9 * C * 2);
@@ -449,9 +516,21 @@ extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float*
   }
   dadd_launch({"conv_cout4_kernel", 2.0 * npix * Cout * 9.0 * C, (double)npix * (2.0 * C + 4.0 * Cout)}, conv_cout4_kernel, dim3((npix + 31) / 32), dim3(256), smem,
                      static_cast<hipStream_t>(stream), static_cast<const half_t*>(x),
-                     static_cast<const half_t*>(w), bias, out_nchw, B, H, W, C, Cout, mode);
+                     static_cast<const half_t*>(w), bias, out_nchw, B, H, W, C, Cout, mode, coef);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
+}
+
+extern "C" int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw,
+                                      int B, int H, int W, int C, int Cout, int mode, void* stream) {
+  DADD_REQUIRE(mode >= 0 && mode <= 2, "conv_cout4: mode must be 0, 1 or 2");
+  return conv_cout4_launch(x, w, bias, out_nchw, B, H, W, C, Cout, mode, nullptr, stream);
+}
+
+extern "C" int dadd_conv_out_ddim_f16(const void* x, const void* w, const float* bias, float* latents,
+                                      const float* coef, int B, int H, int W, int C, int Cout, void* stream) {
+  DADD_REQUIRE(coef != nullptr, "conv_out_ddim: null coefficient row");
+  return conv_cout4_launch(x, w, bias, latents, B, H, W, C, Cout, 3, coef, stream);
 }
 
 extern "C" int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream) {

@@ -341,6 +341,7 @@ class UNetPlan(_Plan):
         # device-side scalars read by the kernels of a captured step: [0] = lambda (delta steering), [1] = CFG scale
         self.params = be.zeros((2,), F32)
         self.params_dev = False      # True while a DdimLoop drives the plan: kernels take lambda from `params`
+        self.ddim_coef = None        # set by DdimLoop for a step without CFG: conv_out applies the DDIM update itself
         self.gn_ws = be.empty((batch * L.GN_MAX_CHUNKS * GROUPS * 2,), F32)
         u = self.prefix
         # ---- time path: linear_1, linear_2, all 22 time_emb_proj concatenated
@@ -562,14 +563,15 @@ class UNetPlan(_Plan):
                           lam_dev=self.params[0:1] if (self.params_dev and self.gates_mode) else None)
 
     def _emit_eps(self, x, w, bias):
-        self.be.conv_cout4(x, w, bias, self.eps_out[self.kv_slot], 0)
+        if self.ddim_coef is not None:      # sampler step without CFG: conv_out and the DDIM update in one launch
+            self.be.conv_out_ddim(x, w, bias, self.lat_in, self.ddim_coef)
+        else:
+            self.be.conv_cout4(x, w, bias, self.eps_out[self.kv_slot], 0)
 
     def _build(self):
         b, s = self.B, self.S
-        x8 = self.pool.get((b, s, s, 8))
-        self.rec(self.be.pack_latents, self.lat_in, x8)
         h = self.pool.get((b, s, s, 320))
-        self.rec(self.be.conv_cin8, x8, self.w("conv_in.weight", pack_conv_cin8), self.f("conv_in.bias"), h)
+        self.rec(self.be.conv_in_nchw, self.lat_in, self.w("conv_in.weight", pack_conv_cin8), self.f("conv_in.bias"), h)
         skips = [h]
         for i in range(4):
             for j in range(2):
@@ -895,18 +897,24 @@ class DdimLoop:
         self.be.copy_(self.u.params, torch.tensor([float(lam), float(guidance)], dtype=F32))
         self.u.prepare_attn2(lam)
 
-    def _one_step(self, lam: float, do_cfg: bool, guidance: float):
+    def _one_step(self, lam: float, do_cfg: bool, guidance: float, keep_eps: bool = False):
+        """``keep_eps``: eps of the step stays readable in ``unet.eps_out`` (traces); otherwise, without CFG, conv_out
+        applies the DDIM update itself (``dadd_conv_out_ddim_f16``) and eps is never stored."""
         u = self.u
         u.params_dev = True
+        fused = not do_cfg and not keep_eps
         try:
             self.be.begin_step(self.table, u.temb_rows, self.coef, self.cur_coef, self.step)
+            u.ddim_coef = self.cur_coef if fused else None
             u.run_slot(0, lam)
             if do_cfg:
                 u.run_slot(1, lam)
-            self.be.ddim_update(u.lat_in, u.eps_out[0], u.eps_out[1] if do_cfg else None, guidance,
-                                self.cur_coef, guidance_dev=u.params[1:2])
+            if not fused:
+                self.be.ddim_update(u.lat_in, u.eps_out[0], u.eps_out[1] if do_cfg else None, guidance,
+                                    self.cur_coef, guidance_dev=u.params[1:2])
         finally:
             u.params_dev = False
+            u.ddim_coef = None
 
     def run(self, lam: float, do_cfg: bool = False, guidance: float = 1.0, use_graph: bool = True,
             trace: Optional[list] = None):
@@ -915,7 +923,7 @@ class DdimLoop:
         self.set_params(lam, guidance)
         if trace is not None or not use_graph:
             for _ in range(self.nsteps):
-                self._one_step(lam, do_cfg, guidance)
+                self._one_step(lam, do_cfg, guidance, keep_eps=trace is not None)
                 if trace is not None:
                     trace.append((self.be.clone(self.u.eps_out[0]), self.be.clone(self.u.lat_in)))
             return

@@ -42,8 +42,10 @@ PROTOTYPES = {
     "dadd_device_info": (C.c_int, [C.c_int, C.POINTER(i64)]),
     "dadd_conv_igemm_f16": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "dadd_conv3x3_cin8_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_conv_in_nchw_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_conv3x3_cout4_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, vp]),
+    "dadd_conv_out_ddim_f16": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_pack_nchw_f32_to_nhwc8_f16": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp,
                                                   vp, vp]),
     "dadd_q_sample_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, i64, vp]),

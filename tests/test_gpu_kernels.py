@@ -515,6 +515,16 @@ def test_thin_convs_and_pack(hip):
     hip.conv_cin8(dev(hip, x8), dev(hip, w), dev(hip, bias), o)
     hip.synchronize()
     close(o, o_ref, 3e-3, 2e-3, "conv_cin8")
+    # the UNet's conv_in straight from the fp32 NCHW latents == pack (scale 1, no matrix) + conv_cin8, same rounding of
+    # the input; ragged pixel count
+    for bb, ss in ((2, 16), (3, 21)):
+        lat2 = rnd((bb, 4, ss, ss), 39, 1.0, F32)
+        o_ref2 = torch.zeros(bb, ss, ss, 320, dtype=F16)
+        REF.conv_in_nchw(lat2, w, bias, o_ref2)
+        o2 = hip.zeros((bb, ss, ss, 320), F16)
+        hip.conv_in_nchw(dev(hip, lat2), dev(hip, w), dev(hip, bias), o2)
+        hip.synchronize()
+        close(o2, o_ref2, 3e-3, 2e-3, "conv_in_nchw")
     for c, co, mode in ((320, 4, 0), (128, 3, 1)):
         x = rnd((b, s, s, c), 39, 1.0)
         w = rnd((co, 9, c), 40, 1 / math.sqrt(9 * c) * (4.0 if mode else 1.0))
@@ -543,6 +553,24 @@ def test_time_rows_and_linear(hip):
         hip.linear_rows(dev(hip, x), dev(hip, w), dev(hip, bias), o, ai, ao)
         hip.synchronize()
         close(o, o_ref, 2e-4, 2e-4, f"linear_rows {m}x{k}x{n}")
+
+
+def test_conv_out_fused_with_ddim_update(hip):
+    """dadd_conv_out_ddim_f16 == dadd_conv3x3_cout4_f16 (mode 0) followed by dadd_ddim_update_f32, bit for bit (same
+    conv arithmetic, the DDIM operations individually rounded in the same order), for a middle step and the last one;
+    ragged pixel count (a block carries 32 pixels)."""
+    b, h, c, co = 3, 21, 320, 4
+    x = rnd((b, h, h, c), 40)
+    w, bias = rnd((co, 9, c), 41, 1 / math.sqrt(9 * c)), rnd((co,), 42, 0.1, F32)
+    lat = rnd((b, co, h, h), 43, 1.0, F32)
+    for coef in (torch.tensor([0.8, 0.6, 0.9, 0.43589]), torch.tensor([0.99, 0.141, -1.0, 0.0])):
+        eps, l_ref, l_fused = hip.zeros((b, co, h, h), F32), dev(hip, lat.clone()), dev(hip, lat.clone())
+        hip.conv_cout4(dev(hip, x), dev(hip, w), dev(hip, bias), eps, 0)
+        hip.ddim_update(l_ref, eps, None, 1.0, dev(hip, coef))
+        hip.conv_out_ddim(dev(hip, x), dev(hip, w), dev(hip, bias), l_fused, dev(hip, coef))
+        hip.synchronize()
+        assert torch.equal(l_fused.cpu(), l_ref.cpu())
+        assert not torch.equal(l_fused.cpu(), lat)
 
 
 def test_ddim_update_is_bit_exact(hip):

@@ -198,6 +198,12 @@ def test_config1_sampler_matches_oracle(full_sd, gates_on):
         z_ref = OS.ddim_sample(full_sd, _ocfg(mod), target, source, feats, 10, lat, **kw)
         img_ref = OS.latents_to_images(full_sd, _ocfg(mod), z_ref)
     assert torch.equal(z.cpu(), z_eager.cpu()), "hipGraph replay must equal eager launches bit for bit"
+    if gates_on:        # no CFG: conv_out applies the DDIM update itself; the traced run keeps eps and a separate update
+        tr = []
+        with torch.no_grad():
+            z_tr = PIPE._ddim_sample_ip(mod, target.to(DEV), source.to(DEV), pix.to(DEV), 10, DEV, latents=lat,
+                                        trace=tr, **kw)
+        assert len(tr) == 10 and torch.equal(z_tr.cpu(), z.cpu()), "fused conv_out + DDIM update must equal the two launches"
     ez = (z.cpu() - z_ref).abs().max().item()
     di = (img.cpu() - img_ref).abs()
     u8 = ((img.cpu() * 255).to(torch.uint8).int() - (img_ref * 255).to(torch.uint8).int()).abs()

@@ -80,6 +80,16 @@ class TorchRefBackend:
         y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, None if bias is None else bias.float(), padding=1)
         out.copy_(y.permute(0, 2, 3, 1).to(out.dtype))
 
+    def conv_in_nchw(self, x, w, bias, out):
+        x8 = torch.zeros(x.shape[0], x.shape[2], x.shape[3], 8, dtype=torch.float16)
+        self.pack_latents(x, x8)
+        self.conv_cin8(x8, w, bias, out)
+
+    def conv_out_ddim(self, x, w, bias, latents, coef):
+        eps = torch.empty_like(latents)
+        self.conv_cout4(x, w, bias, eps, 0)
+        self.ddim_update(latents, eps, None, 1.0, coef)
+
     def conv_cout4(self, x, w, bias, out, mode=0):
         co, _, c = w.shape
         wt = w.float().reshape(co, 3, 3, c).permute(0, 3, 1, 2)
