@@ -155,8 +155,9 @@ int dadd_mse_rows_f32(const float* pred, const float* target, float* out, int B,
 /* ---- normalisation -------------------------------------------------------------------------
  * GroupNorm over a (virtually concatenated) NHWC tensor, optional SiLU, writes the concatenated
  * normalised tensor.  `ws` = fp32 scratch of B*DADD_GN_MAX_CHUNKS*groups*2 floats; with ws_chunks > 0 it already
- * holds [B][ws_chunks][groups][2] partials written by the producing GEMM's epilogue (DADD_EPI_GNSTAT; x2 == NULL,
- * ws_chunks <= 128) and the statistics pass is skipped.
+ * holds [B][ws_chunks][groups][2] partials written by the producing GEMM's epilogue (DADD_EPI_GNSTAT; x2 == NULL)
+ * and the statistics pass is skipped; with ws_chunks > 128 (VAE maps) `ws` needs B*64*groups*2 more floats behind the
+ * partials: a small launch folds them to 64 chunks per sample first.
  * Replaces nn.GroupNorm(+F.silu) in ResnetBlock2D / Transformer2DModel / VAE (+ torch.cat). */
 #define DADD_GN_MAX_CHUNKS 256
 int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2, const float* gamma,

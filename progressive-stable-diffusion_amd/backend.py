@@ -185,7 +185,8 @@ class HipBackend:
         hw = x1.shape[1] * x1.shape[2]
         c1 = x1.shape[-1]
         c2 = 0 if x2 is None else x2.shape[-1]
-        assert out.shape[-1] == c1 + c2 and ws.numel() >= b * (ws_chunks or L.GN_MAX_CHUNKS) * groups * 2
+        need = (ws_chunks + (64 if ws_chunks > 128 else 0)) if ws_chunks else L.GN_MAX_CHUNKS
+        assert out.shape[-1] == c1 + c2 and ws.numel() >= b * need * groups * 2
         L.check(self.lib.dadd_groupnorm_f16(_p(x1), c1, _p(x2), c2, _p(gamma), _p(beta), _p(out),
                                             _p(ws), b, hw, groups, float(eps), int(silu), int(ws_chunks), self.s))
 

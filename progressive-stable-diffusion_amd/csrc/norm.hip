@@ -326,6 +326,22 @@ int dadd_init_norm() {
   return DADD_OK;
 }
 
+// Producer statistics of a large map (VAE: 4096 chunk partials per sample at 512x512): folded down to <= 64 chunks per
+// sample by one small launch, so that every apply block can still combine them itself.  Block (r, b) sums the chunks
+// r, r + R, r + 2R, ... of sample b: thread = (quarter of those chunks, one of the 64 (group, sum | sum of squares)
+// floats), fixed order, fp32 partials of at most a few hundred terms (the apply kernel continues in fp64).
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ red, int nchunk,
+                                                        int R) {
+  __shared__ float part[4][64];
+  const int t = threadIdx.x, idx = t & 63, q = t >> 6;
+  const int r = blockIdx.x, b = blockIdx.y;
+  float a = 0.f;
+  for (int k = r + q * R; k < nchunk; k += 4 * R) a += ws[((size_t)b * nchunk + k) * 64 + idx];
+  part[q][idx] = a;
+  __syncthreads();
+  if (t < 64) red[((size_t)b * R + r) * 64 + t] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+}
+
 extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2,
                                   const float* gamma, const float* beta, void* out, float* ws,
                                   int B, int HW, int groups, float eps, int silu, int ws_chunks, void* stream) {
@@ -362,9 +378,18 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (ws_chunks > 0) {     // partials already written by the producer's epilogue: [B][ws_chunks][groups][2] at ws
-    DADD_REQUIRE(ws_chunks <= 2 * GN_CHUNK_MAX && C2 == 0 && groups == 32, "groupnorm: producer statistics need <= %d chunks, one source, 32 groups", 2 * GN_CHUNK_MAX);
+    DADD_REQUIRE(C2 == 0 && groups == 32, "groupnorm: producer statistics need one source and 32 groups");
     p.nchunk = ws_chunks;
-    p.rows_per_chunk = (HW + ws_chunks - 1) / ws_chunks;
+    if (ws_chunks > 2 * GN_CHUNK_MAX) {       // many chunks: fold them to R <= 64 per sample behind the partials
+      const int R = 64;
+      float* red = ws + (size_t)B * ws_chunks * 64;
+      dadd_launch({"gn_reduce_kernel", 0.0, (double)B * ws_chunks * 256.0}, gn_reduce_kernel, dim3(R, B), dim3(256), 0, s,
+                  (const float*)ws, red, ws_chunks, R);
+      DADD_LAUNCH_CHECK();
+      p.ws = red;
+      p.nchunk = R;
+    }
+    p.rows_per_chunk = (HW + p.nchunk - 1) / p.nchunk;
     const size_t sm2p = ((size_t)2 * C + 2 * groups) * sizeof(float);
     dadd_launch({"gn_apply_kernel<true>", 0.0, (double)B * HW * C * 4.0}, gn_apply_kernel<true>, dim3(nrb, B), dim3(256), (unsigned)sm2p, s, p);
     DADD_LAUNCH_CHECK();

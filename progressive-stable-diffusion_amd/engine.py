@@ -290,8 +290,11 @@ class _Plan:
                 ok = n % cb == 0 and cb % cg == 0 and m % 64 == 0
             nchunk = howo // wm_rows
             # (maps whose (batch, group) slab fits the single-launch LDS GroupNorm keep that path)
-            if ok and howo % wm_rows == 0 and 1 <= nchunk <= 128 and howo * cg * 2 > GN_FUSED_MAX_BYTES:
-                ws = self.be.zeros((out_shape[0] * nchunk * GROUPS * 2,), F32)
+            # (> 128 chunks — the VAE maps — are folded to 64 per sample by gn_reduce_kernel inside dadd_groupnorm_f16:
+            # one small launch instead of a statistics pass over the tensor; `ws` carries the room for them)
+            if ok and howo % wm_rows == 0 and nchunk >= 1 and howo * cg * 2 > GN_FUSED_MAX_BYTES:
+                extra = 64 if nchunk > 128 else 0
+                ws = self.be.zeros((out_shape[0] * (nchunk + extra) * GROUPS * 2,), F32)
                 self.keep.append(ws)
                 self.gn_partials[out.data_ptr()] = (ws, nchunk)
                 gkw = dict(gn_ws=ws, gn_nchunk=nchunk)
@@ -723,7 +726,8 @@ class VaeDecoderPlan(_Plan):
         b, h, w_, cin = x.shape
         cout = self.sd[self.prefix + name + ".conv1.weight"].shape[0]
         g1 = self.gn(x, None, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-6, 1)
-        h1 = self.conv(g1, self.w(name + ".conv1.weight"), (b, h, w_, cout), bias=self.f(name + ".conv1.bias"))
+        h1 = self.conv(g1, self.w(name + ".conv1.weight"), (b, h, w_, cout), bias=self.f(name + ".conv1.bias"),
+                       gn_stats=True)
         self.pool.put(g1)
         g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-6, 1)
         self.pool.put(h1)
@@ -732,7 +736,7 @@ class VaeDecoderPlan(_Plan):
             res = self.conv(x, self.w(name + ".conv_shortcut.weight"), (b, h, w_, cout),
                             bias=self.f(name + ".conv_shortcut.bias"), taps=1, pad=0)
         out = self.conv(g2, self.w(name + ".conv2.weight"), (b, h, w_, cout),
-                        bias=self.f(name + ".conv2.bias"), residual=res)
+                        bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True)
         self.pool.put(g2)
         if res is not x:
             self.pool.put(res)
@@ -749,7 +753,7 @@ class VaeDecoderPlan(_Plan):
         self.rec(self.be.self_attn, qkv.view(b, h * w_, 3 * c), att.view(b, h * w_, c), 1)
         self.pool.put(qkv)
         out = self.conv(att, self.w(name + ".to_out.0.weight"), (b, h, w_, c),
-                        bias=self.f(name + ".to_out.0.bias"), residual=x, taps=1, pad=0)
+                        bias=self.f(name + ".to_out.0.bias"), residual=x, taps=1, pad=0, gn_stats=True)
         self.pool.put(att)
         return out
 
@@ -777,7 +781,7 @@ class VaeDecoderPlan(_Plan):
                 c = h.shape[-1]
                 hn = self.conv(h, self.w(d + f"up_blocks.{i}.upsamplers.0.conv.weight"),
                                (b, h.shape[1] * 2, h.shape[2] * 2, c),
-                               bias=self.f(d + f"up_blocks.{i}.upsamplers.0.conv.bias"), ups=1, pad=1)
+                               bias=self.f(d + f"up_blocks.{i}.upsamplers.0.conv.bias"), ups=1, pad=1, gn_stats=True)
                 self.pool.put(h)
                 h = hn
         g = self.gn(h, None, self.f(d + "conv_norm_out.weight"), self.f(d + "conv_norm_out.bias"), 1e-6, 1)
@@ -822,7 +826,8 @@ class VaeEncoderPlan(VaeDecoderPlan):
                 c = h.shape[-1]
                 hn = self.conv(h, self.w(e + f"down_blocks.{i}.downsamplers.0.conv.weight"),
                                (b, h.shape[1] // 2, h.shape[2] // 2, c),
-                               bias=self.f(e + f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=0)
+                               bias=self.f(e + f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=0,
+                               gn_stats=True)
                 self.pool.put(h)
                 h = hn
         for blk in (lambda x: self._res(e + "mid_block.resnets.0", x),

@@ -764,6 +764,18 @@ def test_igemm_groupnorm_statistics_epilogue(hip, case):
     part3 = torch.stack([oc3.sum(dim=(2, 4)), (oc3 * oc3).sum(dim=(2, 4))], dim=-1)
     assert (ws3.cpu().reshape(b, nch2, 32, 2) - part3).abs().max().item() <= 1e-3 * part3.abs().max().item() + 1e-3
     close(y3, y2.float().cpu(), 3e-3, 3e-3, f"gn from finish partials {case}")
+    if case == "dma128x128":               # many chunks (VAE maps): folded to 64 per sample by gn_reduce_kernel first
+        nbig = 320
+        noise = torch.randn(b, nbig, 32, 2, generator=torch.Generator().manual_seed(5)) * 0.01
+        part_big = noise.clone()
+        part_big[:, :nchunk] += part           # same totals as the real partials, spread over 320 chunks
+        part_big[:, -1] -= noise.sum(dim=1)
+        wsb = hip.zeros((b * (nbig + 64) * 64,), F32)
+        wsb[: b * nbig * 64].copy_(part_big.reshape(-1))
+        yb = hip.zeros((b, hw, hw, n), F16)
+        hip.groupnorm(o, None, dev(hip, gamma), dev(hip, beta), yb, wsb, 32, 1e-5, 1, ws_chunks=nbig)
+        hip.synchronize()
+        close(yb, y2.float().cpu(), 3e-3, 3e-3, "gn from 320 chunk partials (reduced)")
     with pytest.raises(ValueError):        # contract: the chunk count must match the path that writes the partials
         hip.igemm(dev(hip, x), dev(hip, w), o, taps=taps, pad=taps // 9, flags=L.EPI_GNSTAT, tile_m=tm, tile_n=tn,
                   gn_ws=hip.zeros((b * (nchunk + 1) * 64,), F32), gn_nchunk=nchunk + 1)
