@@ -205,9 +205,14 @@ int dadd_tri_xattn_f16(const void* q, const void* kv, void* out, const float* ga
  * H*W % 128 == 0, C % 320 == 0.  Replaces to_q + SplitInjectionAttentionProcessor.__call__:142-181 + to_out
  * (src/models/attention_processor_routing_gates.py:118-190) — exact algebra, other rounding points.
  * ln_stats_out (or NULL): LayerNorm row partials of `out`, [C / 80][B*HW][2] floats, as DADD_EPI_LNSTAT writes them
- * (the GEGLU projection behind norm3 then takes them through ln_stats_in). */
+ * (the GEGLU projection behind norm3 then takes them through ln_stats_in).
+ * ln_stats_in (or NULL): norm2 folded into the score GEMM — x is then the UN-normalised hidden state, ln_stats_in its
+ * row partials [ln_parts_in][B*HW][2] from the producer (DADD_EPI_LNSTAT), mcat carries gamma (mcat[b][n][c] * gamma_c),
+ * ln_c1[b][n] = sum_c of those fp16 values, ln_d[b][n] = sum_c mcat0[b][n][c] * beta_c:
+ * S = rstd_m (x mcat^T - mu_m c1) + d (BasicTransformerBlock.norm2 -> attn2.to_q, same algebra as DADD_EPI_LNFOLD). */
 int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const float* bias,
-                         const void* residual, void* out, float* ln_stats_out, int B, int HW, int C,
+                         const void* residual, void* out, float* ln_stats_out, const float* ln_stats_in,
+                         int ln_parts_in, const float* ln_c1, const float* ln_d, float ln_eps, int B, int HW, int C,
                          void* stream);
 
 /* ---- sampler glue --------------------------------------------------------------------------

@@ -211,16 +211,24 @@ class HipBackend:
                                             b, n, heads, c // heads, kv.shape[1], kv.stride(1),
                                             self.s))
 
-    def attn2_fused(self, x, mcat, vw, bias, residual, out, ln_stats_out=None):
+    def attn2_fused(self, x, mcat, vw, bias, residual, out, ln_stats_out=None, ln_stats_in=None, ln_c1=None, ln_d=None,
+                    ln_eps=1e-5):
         """x, residual, out [B,HW,C]; mcat [B,384,C]; vw [B,C,384] (include/dadd_hip.h); ``ln_stats_out`` [C/80][B*HW][2]
-        fp32: LayerNorm row partials of ``out`` for the linear behind the next LayerNorm."""
+        fp32: LayerNorm row partials of ``out`` for the linear behind the next LayerNorm.  ``ln_stats_in`` [P][B*HW][2]
+        with ``ln_c1`` / ``ln_d`` [B,384]: norm2 folded in (x un-normalised, mcat carrying gamma)."""
         b, hw, c = x.shape
         assert mcat.shape == (b, 384, c) and vw.shape == (b, c, 384) and out.shape == x.shape
         if ln_stats_out is not None:
             assert ln_stats_out.shape == (c // 80, b * hw, 2) and ln_stats_out.dtype == torch.float32 \
                 and ln_stats_out.is_contiguous()
+        parts = 0
+        if ln_stats_in is not None:
+            assert ln_stats_in.dim() == 3 and ln_stats_in.shape[1:] == (b * hw, 2) and ln_stats_in.dtype == torch.float32 \
+                and ln_stats_in.is_contiguous() and ln_c1.shape == (b, 384) and ln_d.shape == (b, 384) \
+                and ln_c1.dtype == ln_d.dtype == torch.float32 and ln_c1.is_contiguous() and ln_d.is_contiguous()
+            parts = ln_stats_in.shape[0]
         L.check(self.lib.dadd_attn2_fused_f16(_p(x), _p(mcat), _p(vw), _p(bias), _p(residual), _p(out), _p(ln_stats_out),
-                                              b, hw, c, self.s))
+                                              _p(ln_stats_in), parts, _p(ln_c1), _p(ln_d), float(ln_eps), b, hw, c, self.s))
 
     def timestep_features(self, t, out):
         assert t.dtype == torch.int64 and out.dtype == torch.float32

@@ -45,6 +45,13 @@ struct Attn2Args {
   const half_t* residual;  // [B*HW][C]
   half_t* out;             // [B*HW][C]
   float* ln_stats;         // null, or LayerNorm row partials of `out`: [C / 80][B*HW][2] (DADD_EPI_LNSTAT of igemm)
+  // LayerNorm (norm2) folded into the score GEMM: x is the UN-normalised hidden state, mcat carries gamma,
+  //   S = rstd_m (x mcat^T - mu_m c1) + d,   c1[b][n] = sum_c mcat[b][n][c],  d[b][n] = sum_c mcat0[b][n][c] beta_c
+  const float* ln_in;      // null (no fold), or the row partials of x written by its producer: [ln_parts][B*HW][2]
+  const float* ln_c1;      // [B][384]
+  const float* ln_d;       // [B][384]
+  float ln_eps;
+  int ln_parts;
   int B, HW, C;
 };
 
@@ -103,6 +110,32 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
   for (int j = 0; j < 12; ++j)
 #pragma unroll
     for (int i = 0; i < MI; ++i) acc[j][i] = f4{0.f, 0.f, 0.f, 0.f};
+  // folded LayerNorm: row mean / rstd of this lane's MI rows from the producer's partials (loaded under the first DMA)
+  const bool fold = p.ln_in != nullptr;
+  float lmu[MI], lrs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) lmu[i] = 0.f, lrs[i] = 1.f;
+  if (fold) {
+    const dadd_f2* st = reinterpret_cast<const dadd_f2*>(p.ln_in);
+    const size_t mtot = (size_t)p.B * p.HW;
+    float sa[MI], sq[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) sa[i] = sq[i] = 0.f;
+    for (int pp = 0; pp < p.ln_parts; ++pp)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const dadd_f2 v = st[(size_t)pp * mtot + m0 + wm * WMR + i * 16 + mc];
+        sa[i] += v[0];
+        sq[i] += v[1];
+      }
+    const float inv = __builtin_amdgcn_rcpf((float)C);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const float mu = sa[i] * inv;
+      lmu[i] = mu;
+      lrs[i] = rsqrtf(fmaxf(sq[i] * inv - mu * mu, 0.f) + p.ln_eps);
+    }
+  }
   int fa[2], fb[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -127,6 +160,16 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  // c1 / d of this lane's 12 column quads (issued before the barrier and the first VW DMA: their latency hides there)
+  f4 fc1[12], fd[12];
+  if (fold) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int k = wn * 192 + j * 16 + g * 4;
+      fc1[j] = *reinterpret_cast<const f4*>(p.ln_c1 + (size_t)b * NS + k);
+      fd[j] = *reinterpret_cast<const f4*>(p.ln_d + (size_t)b * NS + k);
     }
   }
   __syncthreads();                                     // all fragment reads of phase 1 done: LDS is free
@@ -161,7 +204,8 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
     const int swz = (row >> 1) & 7;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
-      const f4 v = acc[j][i];
+      f4 v = acc[j][i];
+      if (fold) v = lrs[i] * (v - lmu[i] * fc1[j]) + fd[j];
       float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -261,8 +305,9 @@ int dadd_init_attn2_fused() {
 }
 
 extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const float* bias,
-                                    const void* residual, void* out, float* ln_stats_out, int B, int HW, int C,
-                                    void* stream) {
+                                    const void* residual, void* out, float* ln_stats_out, const float* ln_stats_in,
+                                    int ln_parts_in, const float* ln_c1, const float* ln_d, float ln_eps, int B, int HW,
+                                    int C, void* stream) {
   DADD_REQUIRE(x && mcat && vw && residual && out, "attn2_fused: null pointer");
   DADD_REQUIRE(B > 0 && HW > 0 && HW % 128 == 0, "attn2_fused: H*W=%d must be a multiple of 128", HW);
   DADD_REQUIRE(C > 0 && C % BN2 == 0 && C % BK == 0, "attn2_fused: C=%d must be a multiple of 320", C);
@@ -278,6 +323,13 @@ extern "C" int dadd_attn2_fused_f16(const void* x, const void* mcat, const void*
   a.residual = static_cast<const half_t*>(residual);
   a.out = static_cast<half_t*>(out);
   a.ln_stats = ln_stats_out;
+  DADD_REQUIRE(ln_stats_in == nullptr || (ln_parts_in > 0 && ln_c1 && ln_d && ln_eps > 0.f),
+               "attn2_fused: a folded LayerNorm needs the row partials of x, their count, c1, d and eps");
+  a.ln_in = ln_stats_in;
+  a.ln_parts = ln_parts_in;
+  a.ln_c1 = ln_c1;
+  a.ln_d = ln_d;
+  a.ln_eps = ln_eps;
   a.B = B; a.HW = HW; a.C = C;
   // algorithmic work: two GEMMs against the folded conditioning (K = C, N = 384 and K = 384, N = C)
   const double flop = 4.0 * (double)B * HW * C * 384.0;

@@ -393,7 +393,11 @@ class UNetPlan(_Plan):
                     ap = f"{u}{site}.transformer_blocks.0.attn2"
                     self.a2[site] = dict(
                         wq=self.dev(sd[ap + ".to_q.weight"].float()), wo=self.dev(sd[ap + ".to_out.0.weight"].float()),
-                        mcat=be.zeros((batch, 384, c), F16), vw=be.zeros((batch, c, 384), F16))
+                        mcat=be.zeros((batch, 384, c), F16), vw=be.zeros((batch, c, 384), F16),
+                        # norm2 folded into the score GEMM (set by _transformer when the producer supplies row partials)
+                        fold=False, ln_c1=be.zeros((batch, 384), F32), ln_d=be.zeros((batch, 384), F32),
+                        gamma=self.dev(sd[f"{u}{site}.transformer_blocks.0.norm2.weight"].float()),
+                        beta=self.dev(sd[f"{u}{site}.transformer_blocks.0.norm2.bias"].float()))
         # ---- I/O
         self.lat_in = be.zeros((batch, 4, side, side), F32)
         self.eps_out = [be.zeros((batch, 4, side, side), F32) for _ in range(2)]
@@ -507,20 +511,27 @@ class UNetPlan(_Plan):
         fused2 = site in self.a2
         h2 = self.conv(att, self.w(tb + ".attn1.to_out.0.weight"), shp,
                        bias=self.f(tb + ".attn1.to_out.0.bias"), residual=hs, taps=1, pad=0,
-                       ln_stats=ext and not fold2 and not fused2)
+                       ln_stats=ext and not fold2)
         self.pool.put(hs)
         # attn2 (DADD cross-attention)
         st3 = None
         if fused2:                   # one kernel: x (W_q K^T) -> 24 softmaxes -> P (V W_o^T) + bias + residual
-            lnx = ln_of(h2, ".norm2")
             st = self.a2[site]
+            st2 = self.ln_partials.get(h2.data_ptr())
+            kw2 = {}
+            if st2 is not None:          # norm2 folded into the score GEMM: mcat carries gamma (prepare_attn2)
+                st["fold"] = True
+                lnx = h2
+                kw2 = dict(ln_stats_in=st2, ln_c1=st["ln_c1"], ln_d=st["ln_d"], ln_eps=1e-5)
+            else:
+                lnx = ln_of(h2, ".norm2")
             h3 = self.pool.get(shp)
             if ext and not fold3 and c % 80 == 0:
                 st3 = self.be.zeros((c // 80, m_rows, 2), F32)
                 self.keep.append(st3)
+                kw2["ln_stats_out"] = st3
             self.rec(self.be.attn2_fused, lnx.view(b, h * w_, c), st["mcat"], st["vw"],
-                     self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c),
-                     **({"ln_stats_out": st3} if st3 is not None else {}))
+                     self.f(tb + ".attn2.to_out.0.bias"), h2.view(b, h * w_, c), h3.view(b, h * w_, c), **kw2)
         else:
             st2 = self.ln_partials.get(h2.data_ptr())
             if fold2 or st2 is not None:
@@ -662,7 +673,13 @@ class UNetPlan(_Plan):
                 if float(lam) == 0.0:      # routing_gates.py:160,177-178: the delta pathway is skipped, not scaled —
                     m[:, :, 2] = 0.0       # zero scores and zero values: garbage (NaN) delta tokens cannot leak
                     v[:, :, :, 2] = 0.0
-                st["mcat"].copy_(m.reshape(B, 384, c))
+                m = m.reshape(B, 384, c)
+                if st["fold"]:             # LayerNorm 2 folded in: S = rstd (x (gamma o M)^T - mu c1) + M beta
+                    st["ln_d"].copy_((m * st["beta"]).sum(dim=-1))
+                    m = m * st["gamma"]
+                st["mcat"].copy_(m)
+                if st["fold"]:             # c1 sums the ROUNDED rows, so that the mean term cancels exactly
+                    st["ln_c1"].copy_(st["mcat"].float().sum(dim=-1))
                 st["vw"].copy_(v.reshape(B, c, 384))
         self._a2_dirty, self._a2_lam = False, float(lam)
 

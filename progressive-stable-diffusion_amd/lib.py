@@ -57,7 +57,7 @@ PROTOTYPES = {
     "dadd_layernorm_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
     "dadd_self_attn_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, vp]),
-    "dadd_attn2_fused_f16": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_attn2_fused_f16": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, f32, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_tri_xattn_f16": (C.c_int, [vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
     "dadd_timestep_features_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

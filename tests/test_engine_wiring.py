@@ -136,6 +136,32 @@ def test_unet_plan_layernorm_statistics_from_producer(unet_sd, lam, monkeypatch)
     assert sum(1 for fn, _, _ in plan2.ops if getattr(fn, "__name__", "") == "layernorm") == 48
 
 
+def test_unet_plan_fused_attn2_with_norm2_folded(unet_sd, monkeypatch):
+    """Fused attn2 sites (maps of >= 128 tokens): norm2 is folded into the score GEMM of attn2_fused — the hidden state goes
+    in un-normalised with the row partials of the attn1 out-projection, mcat carries gamma, c1 / d come from
+    prepare_attn2 — and the kernel writes the partials for norm3.  No LayerNorm launch is left at those sites; lambda
+    changes re-fold the conditioning; the result is the oracle's."""
+    monkeypatch.setattr(E, "LN_FOLD", "auto")
+    monkeypatch.setattr(E, "fold_here", lambda *a, **k: False)
+    monkeypatch.setattr(E, "LN_STATS_MAX_PARTS", 1000)
+    monkeypatch.setattr(E, "A2_MIN_TILES", 1)
+    torch.manual_seed(4)
+    b, s = 1, 16                       # 256 / 64 tokens at the two upper levels: the 320-channel sites fuse
+    plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    assert len(plan.a2) >= 1 and all(st["fold"] for st in plan.a2.values())
+    names = [getattr(fn, "__name__", "") for fn, _, _ in plan.ops]
+    assert names.count("layernorm") == 0
+    fused = [k for fn, _, k in plan.ops if getattr(fn, "__name__", "") == "attn2_fused"]
+    assert len(fused) == len(plan.a2) and all(k.get("ln_stats_in") is not None and k.get("ln_stats_out") is not None for k in fused)
+    x, cond = torch.randn(b, 4, s, s), torch.randn(b, 48, 768) * 0.5
+    t = torch.tensor([700])
+    for lam in (3.0, 0.0):
+        with torch.no_grad():
+            ref = unet_forward(unet_sd, x, t, cond, delta_scale=lam)
+            got = plan.forward(x, t, cond, lam=lam)
+        assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item()), lam
+
+
 def test_unet_plan_baseline_mode(full_sd):
     torch.manual_seed(2)
     sd = full_sd

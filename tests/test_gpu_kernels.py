@@ -461,6 +461,24 @@ def test_attn2_fused(hip, b, hw, c):
     oc = o.float().cpu().reshape(b * hw, c // 80, 80)
     want = torch.stack([oc.sum(-1), (oc * oc).sum(-1)], dim=-1).permute(1, 0, 2)
     assert (st.cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-4
+    # norm2 folded into the score GEMM: un-normalised x with a common offset per row, its row partials (4 parts, as the
+    # producing GEMM writes them), mcat carrying gamma, c1 / d — against LayerNorm -> the unfolded kernel arithmetic
+    import torch.nn.functional as Fn
+    gen = torch.Generator().manual_seed(95)
+    xr = (x.float() * 1.5 + 2.0 * torch.randn(b, hw, 1, generator=gen)).to(F16)
+    gamma, beta = 1.0 + 0.2 * torch.randn(c, generator=gen), 0.2 * torch.randn(c, generator=gen)
+    m0 = mcat.float()
+    mg = (m0 * gamma).to(F16)
+    c1, dvec = mg.float().sum(-1), (m0 * beta).sum(-1)
+    xp = xr.float().reshape(b * hw, 4, c // 4)
+    st_in = torch.stack([xp.sum(-1), (xp * xp).sum(-1)], dim=-1).permute(1, 0, 2).contiguous()
+    o_ref2 = torch.zeros(b, hw, c, dtype=F16)
+    REF.attn2_fused(Fn.layer_norm(xr.float(), (c,), gamma, beta, 1e-5).to(F16), mcat, vw, bias, res, o_ref2)
+    o_f = hip.zeros((b, hw, c), F16)
+    hip.attn2_fused(dev(hip, xr), dev(hip, mg), dev(hip, vw), dev(hip, bias), dev(hip, res), o_f,
+                    ln_stats_in=dev(hip, st_in), ln_c1=dev(hip, c1.contiguous()), ln_d=dev(hip, dvec.contiguous()))
+    hip.synchronize()
+    close(o_f, o_ref2, 8e-3, 6e-3, f"attn2_fused with norm2 folded {b}x{hw}x{c}")
     with pytest.raises(ValueError):
         hip.attn2_fused(dev(hip, x[:, :64]), dev(hip, mcat), dev(hip, vw), None, dev(hip, res[:, :64]),
                         hip.zeros((b, 64, c), F16))          # fewer than 128 tokens per sample

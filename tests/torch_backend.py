@@ -198,9 +198,14 @@ class TorchRefBackend:
         p = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1)
         out.copy_((p @ v).transpose(1, 2).reshape(b, n, c).to(out.dtype))
 
-    def attn2_fused(self, x, mcat, vw, bias, residual, out, ln_stats_out=None):
+    def attn2_fused(self, x, mcat, vw, bias, residual, out, ln_stats_out=None, ln_stats_in=None, ln_c1=None, ln_d=None,
+                    ln_eps=1e-5):
         b, hw, c = x.shape
         s = torch.einsum("bmc,bkc->bmk", x.float(), mcat.float())            # log2(e)/sqrt(d) folded in
+        if ln_stats_in is not None:     # norm2 folded in: S = rstd (x mcat^T - mu c1) + d
+            st = ln_stats_in.sum(dim=0).reshape(b, hw, 2) / c
+            mu, var = st[..., 0:1], (st[..., 1:2] - st[..., 0:1] ** 2).clamp_min(0.0)
+            s = torch.rsqrt(var + ln_eps) * (s - mu * ln_c1.float()[:, None, :]) + ln_d.float()[:, None, :]
         pr = torch.softmax(s.view(b, hw, 24, 16) * math.log(2.0), dim=-1).view(b, hw, 384)
         pr = pr.to(torch.float16).float()                                     # P is stored in fp16
         y = torch.einsum("bmk,bnk->bmn", pr, vw.float())
