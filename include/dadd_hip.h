@@ -42,6 +42,12 @@ extern "C" {
                                rounded fp16 values over each block of tile_n/2 columns) into ln_stats_out [ln_parts][M][2],
                                ln_parts = N / (tile_n/2): the linear that consumes LayerNorm(out) takes them through
                                ln_stats_in and needs neither a LayerNorm launch nor statistics of its own */
+#define DADD_PRE_GN 8192      /* GroupNorm (32 groups) of the INPUT applied on the way in: x is the un-normalised tensor,
+                                gn_in_ws its chunk partials [B][gn_in_nchunk][32][2] (a producer's DADD_EPI_GNSTAT), gn_in_gamma /
+                                gn_in_beta the affine; the 3x3 halo kernel normalises the halo in LDS (its loader waves, one
+                                16-byte piece per lane and tap) — no GroupNorm launch, no normalised copy.  3x3 / stride 1 on
+                                64-, 32- or 16-wide maps with 128x160 tiles, one source, Cin <= 1024 */
+#define DADD_PRE_GN_SILU 16384 /* ... followed by SiLU (ResnetBlock2D.norm1/2 + nonlinearity) */
 #define DADD_EPI_GNSTAT 2048 /* the epilogue also writes the GroupNorm chunk partials of its OUTPUT (32 groups) into
                                gn_ws [B][gn_nchunk][32][2] (sum, sum of squares per row block of tile_m/2 rows): the
                                consuming dadd_groupnorm_f16 then skips its statistics pass (ws_chunks = gn_nchunk) */
@@ -103,6 +109,11 @@ typedef struct {
   const float* ln_stats_in;      /* with DADD_EPI_LNFOLD: row partials [ln_parts_in][M][2] of x written by the GEMM that
                                     produced x (its DADD_EPI_LNSTAT); NULL: the kernel sums the rows itself */
   int32_t ln_parts_out, ln_parts_in;
+  const float* gn_in_ws;         /* DADD_PRE_GN (see the flag) */
+  const float* gn_in_gamma;
+  const float* gn_in_beta;
+  int32_t gn_in_nchunk;
+  float gn_in_eps;
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 

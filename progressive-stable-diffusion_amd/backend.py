@@ -140,8 +140,9 @@ class HipBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None):
         """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU).
+        ``gn_in`` = (partials [B*nchunk*64] fp32, nchunk, gamma, beta, eps) with PRE_GN: GroupNorm of x on the way in.
         ``ln_stats_out`` [P][M][2] fp32 (EPI_LNSTAT): row partials of the output, P = N / (tile_n/2);
         ``ln_stats_in`` [P'][M][2] (EPI_LNFOLD): the partials of x written by its producer."""
         b, hi, wi, c1 = x.shape
@@ -175,6 +176,14 @@ class HipBackend:
             assert flags & L.EPI_LNFOLD and ln_stats_in.dtype == torch.float32 and ln_stats_in.dim() == 3 \
                 and ln_stats_in.shape[1:] == (b * hi * wi, 2) and ln_stats_in.is_contiguous()
             d.ln_parts_in = ln_stats_in.shape[0]
+        d.gn_in_ws = d.gn_in_gamma = d.gn_in_beta = None
+        d.gn_in_nchunk, d.gn_in_eps = 0, 0.0
+        if gn_in is not None:
+            ws_in, nch_in, gam, bet, eps_in = gn_in
+            assert flags & L.PRE_GN and ws_in.dtype == gam.dtype == bet.dtype == torch.float32 \
+                and ws_in.numel() >= b * nch_in * 64 and gam.numel() == c1 and bet.numel() == c1
+            d.gn_in_ws, d.gn_in_gamma, d.gn_in_beta = _p(ws_in), _p(gam), _p(bet)
+            d.gn_in_nchunk, d.gn_in_eps = int(nch_in), float(eps_in)
         if partial is not None:
             assert partial.numel() >= splitk * b * ho * wo * n
         L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))

@@ -53,6 +53,7 @@ constexpr int HALO_BYTES = HALO_MAX_PIX * 128;
 constexpr int DUMP_OFF = W_RING + 2 * HALO_BYTES;
 constexpr int GN_OFF = DUMP_OFF + 4 * 1024;        // statistics scratch of the epilogue (igemm_epilogue.h)
 constexpr int SMEM_BYTES = GN_OFF + 4 * 1024;
+constexpr int SMEM_BYTES_GNIN = GN_OFF + 8 * 1024;  // DADD_PRE_GN: scale / shift of <= 1024 input channels (the whole 160 KB)
 constexpr bool DO_LOAD = DADD_IGEMM_EXP != 5 && DADD_IGEMM_EXP != 6;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -73,7 +74,16 @@ constexpr unsigned OOB = 0x80000000u;
 // for the one-wave build at W = 64 / 32 / 16 — no gain: the tap time is set by the LDS-DMA stream (three weight tiles
 // = 60 KB in flight per CU at ~1.5 us of loaded latency), not by stalls of the MFMA waves.  Kept as the A/B build
 // (DADD_TUNE_SHALLOW on a 3x3 / stride-1 conv), not the default.
-template <int WT, bool DUO>
+//
+// GNIN (DADD_PRE_GN): GroupNorm (+ SiLU) of the INPUT applied to the halo in LDS.  While the prologue DMA is in flight
+// the four MFMA waves (idle then) reduce the chunk partials of the sample to mean / rstd — each wave its own eight
+// groups, the arithmetic of gn_apply_kernel — and write scale / shift of every input channel to an LDS table (8 KB
+// behind the dump area: Cin <= 1024).  Every loader wave then normalises the halo piece IT loaded, one tap after
+// issuing it (its own counted wait has covered it): one ds_read_b128 of data, four of table, ~80 vector instructions,
+// one ds_write_b128 per lane and tap — affordable because the tap time is set by the DMA stream, not by issue slots.
+// Out-of-image pixels stay the zeros the DMA wrote (the conv pads the NORMALISED tensor).  Replaces a gn_apply
+// launch (7 us + a read and a write of the tensor) per conv.
+template <int WT, bool DUO, bool GNIN = false>
 __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const IgemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -121,12 +131,14 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
     // index is a constant (a runtime-indexed table would land in scratch) and the loader waves — which share
     // their SIMD's VALU issue with an MFMA wave — run no vector arithmetic in the steady state.
     unsigned hv1[9], hv2[9];
+    [[maybe_unused]] unsigned okmask = 0;           // GNIN: bit sl = this lane's pixel of slot sl lies inside the image
 #pragma unroll
     for (int sl = 0; sl < 9; ++sl) {
       const int px = (sl * 4 + wave) * 8 + lrow;
       const int hy = px / WH, hx = px - hy * WH;
       const int y = y0 - 1 + hy, x = hx - 1;
       const bool ok = px < HP && y >= 0 && y < H && x >= 0 && x < W;
+      okmask |= ok ? 1u << sl : 0u;
       const int chunk = lch ^ (px & 7);
       const int pix = (b * H + y) * W + x;
       hv1[sl] = ok ? (unsigned)((pix * p.C1 + chunk * 8) * 2) : OOB;
@@ -164,6 +176,28 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
       wk_c += ww ? BK : 0;
     };
 
+    // GNIN: normalise (+ SiLU) the piece of slot SL of chunk `cp` that this wave loaded, in place
+    [[maybe_unused]] auto gn_piece = [&](int cp, auto SLC) {
+      constexpr int SL = decltype(SLC)::value;
+      if (cp >= c1 || (SL * 4 + wave) >= live_pieces) return;        // wave-uniform: no such piece
+      char* ptr = smem + W_RING + ((cp - c0) & 1) * HALO_BYTES + (SL * 4 + wave) * 1024 + lane * 16;
+      const int px = (SL * 4 + wave) * 8 + lrow;
+      const int ch0 = cp * BK + (lch ^ (px & 7)) * 8;                 // first of this lane's eight input channels
+      const h8 v = *reinterpret_cast<const h8*>(ptr);
+      const f4* tb = reinterpret_cast<const f4*>(smem + GN_OFF) + ch0 / 2;   // table [Cin][2] floats: (scale, shift)
+      const f4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+      const float sc[8] = {t0[0], t0[2], t1[0], t1[2], t2[0], t2[2], t3[0], t3[2]};
+      const float sh[8] = {t0[1], t0[3], t1[1], t1[3], t2[1], t2[3], t3[1], t3[3]};
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e] * sc[e] + sh[e];
+        if (p.flags & DADD_PRE_GN_SILU) f = dadd_silu(f);
+        o[e] = (half_t)f;
+      }
+      if ((okmask >> SL) & 1u) *reinterpret_cast<h8*>(ptr) = o;      // padding pixels keep their zeros
+    };
+
     // ---- prologue: the whole halo of the first chunk, weight tiles 0, 1, 2
     issue_halo(c0, std::integral_constant<int, 0>{});
     issue_halo(c0, std::integral_constant<int, 1>{});
@@ -177,7 +211,19 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
     issue_w();
     issue_w();
     issue_w();
+    if constexpr (GNIN) __builtin_amdgcn_s_barrier();            // the MFMA waves have written the scale / shift table
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");   // everything but weight tile 2
+    if constexpr (GNIN) {      // slots 0..7 of the first chunk (slot 8 follows the rule of the stream: one tap later)
+      gn_piece(c0, std::integral_constant<int, 0>{});
+      gn_piece(c0, std::integral_constant<int, 1>{});
+      gn_piece(c0, std::integral_constant<int, 2>{});
+      gn_piece(c0, std::integral_constant<int, 3>{});
+      gn_piece(c0, std::integral_constant<int, 4>{});
+      gn_piece(c0, std::integral_constant<int, 5>{});
+      gn_piece(c0, std::integral_constant<int, 6>{});
+      gn_piece(c0, std::integral_constant<int, 7>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     // ---- LDS-DMA stream.  Iteration g (after its barrier, when the ring slot of tile g - 1 is free) issues halo
@@ -191,9 +237,17 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
     // buffer_load into VGPRs two taps ahead, ds_write_b128 — 171 us, the loaders became the critical path.)
     auto ltap = [&](int c, auto SLC) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");
+      if constexpr (GNIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last tap's normalised piece is written
       __builtin_amdgcn_s_barrier();
       issue_halo(c + 1, SLC);
       issue_w();
+      if constexpr (GNIN) {    // BEHIND the DMA issue (the stream is the critical path; this runs while it is in flight):
+        // the piece issued one tap ago has landed (the counted wait above) — slot SL - 1 of chunk c + 1, or slot 8 of
+        // chunk c.  It becomes visible at the barrier after next; its first reader comes at least two taps later.
+        constexpr int SL = decltype(SLC)::value;
+        if constexpr (SL == 0) gn_piece(c, std::integral_constant<int, 8>{});
+        else gn_piece(c + 1, std::integral_constant<int, (SL + 8) % 9>{});
+      }
     };
     for (int c = c0; c < c1; ++c) {
       ltap(c, std::integral_constant<int, 0>{});
@@ -324,6 +378,47 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
     igemm_epilogue<J, 4, 64, WN>(p, acc, m0, n0, wm, wn, lane, z, smem, nullptr, nullptr, smem + GN_OFF);
     return;
   }
+  if constexpr (GNIN) {
+    // mean / rstd of this wave's eight groups from the chunk partials (order and precision of gn_apply_kernel), then
+    // scale / shift of their channels into the LDS table; the loader waves read it after the barrier below
+    float* tab = reinterpret_cast<float*>(smem + GN_OFF);
+    const int cg = Cin >> 5;
+    const int g = wave * 8 + (lane >> 3), sub = lane & 7;
+    double a = 0.0, q = 0.0;
+    for (int k = sub; k < p.gni_nchunk; k += 32) {
+      dadd_f2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = min(k + 8 * u, p.gni_nchunk - 1);
+        v[u] = *reinterpret_cast<const dadd_f2*>(p.gni_ws + (((size_t)b * p.gni_nchunk + kk) * 32 + g) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k + 8 * u < p.gni_nchunk) {
+          a += (double)v[u][0];
+          q += (double)v[u][1];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    const double n = (double)(H * W) * (double)cg;
+    const double mu = a / n;
+    double var = q / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float mean_f = (float)mu, rstd_f = (float)(1.0 / sqrt(var + (double)p.gni_eps));
+    for (int cc = sub; cc < cg; cc += 8) {
+      const int ch = g * cg + cc;
+      const float sc = rstd_f * p.gni_gamma[ch];
+      tab[2 * ch] = sc;
+      tab[2 * ch + 1] = p.gni_beta[ch] - mean_f * sc;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   __builtin_amdgcn_s_barrier();                     // halo of the first chunk and weight tiles 0..2 landed
   __builtin_amdgcn_sched_barrier(0);
   h8 xa0[4], xa1[4], wb0[J], wb1[J];
@@ -396,10 +491,10 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
 #endif
 }
 
-template <int WT, bool DUO>
+template <int WT, bool DUO, bool GNIN = false>
 int set_attr_halo() {
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WT, DUO>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<WT, DUO, GNIN>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GNIN ? SMEM_BYTES_GNIN : SMEM_BYTES));
   return DADD_OK;
 }
 
@@ -412,6 +507,9 @@ int dadd_init_conv_halo() {
   if (rc == DADD_OK) rc = set_attr_halo<64, true>();
   if (rc == DADD_OK) rc = set_attr_halo<32, true>();
   if (rc == DADD_OK) rc = set_attr_halo<16, true>();
+  if (rc == DADD_OK) rc = set_attr_halo<64, false, true>();
+  if (rc == DADD_OK) rc = set_attr_halo<32, false, true>();
+  if (rc == DADD_OK) rc = set_attr_halo<16, false, true>();
   return rc;
 }
 
@@ -431,14 +529,18 @@ int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s) {
   dim3 grid(a.mtiles * a.ntiles, nsplit);
   const double flop = dadd_igemm_flop(a), bytes = dadd_igemm_bytes(a);
   const bool duo = (a.flags & DADD_TUNE_SHALLOW) != 0;   // A/B switch: measured equal to the one-wave build (see the kernel comment)
-  if (duo) {
-    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, true>", flop, bytes}, conv3x3_halo_kernel<64, true>, grid, dim3(768), SMEM_BYTES, s, a);
-    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, true>", flop, bytes}, conv3x3_halo_kernel<32, true>, grid, dim3(768), SMEM_BYTES, s, a);
-    else dadd_launch({"conv3x3_halo_kernel<16, true>", flop, bytes}, conv3x3_halo_kernel<16, true>, grid, dim3(768), SMEM_BYTES, s, a);
+  if (a.flags & DADD_PRE_GN) {
+    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, false, true>", flop, bytes}, conv3x3_halo_kernel<64, false, true>, grid, dim3(512), SMEM_BYTES_GNIN, s, a);
+    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, false, true>", flop, bytes}, conv3x3_halo_kernel<32, false, true>, grid, dim3(512), SMEM_BYTES_GNIN, s, a);
+    else dadd_launch({"conv3x3_halo_kernel<16, false, true>", flop, bytes}, conv3x3_halo_kernel<16, false, true>, grid, dim3(512), SMEM_BYTES_GNIN, s, a);
+  } else if (duo) {
+    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, true, false>", flop, bytes}, conv3x3_halo_kernel<64, true>, grid, dim3(768), SMEM_BYTES, s, a);
+    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, true, false>", flop, bytes}, conv3x3_halo_kernel<32, true>, grid, dim3(768), SMEM_BYTES, s, a);
+    else dadd_launch({"conv3x3_halo_kernel<16, true, false>", flop, bytes}, conv3x3_halo_kernel<16, true>, grid, dim3(768), SMEM_BYTES, s, a);
   } else {
-    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, false>", flop, bytes}, conv3x3_halo_kernel<64, false>, grid, dim3(512), SMEM_BYTES, s, a);
-    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, false>", flop, bytes}, conv3x3_halo_kernel<32, false>, grid, dim3(512), SMEM_BYTES, s, a);
-    else dadd_launch({"conv3x3_halo_kernel<16, false>", flop, bytes}, conv3x3_halo_kernel<16, false>, grid, dim3(512), SMEM_BYTES, s, a);
+    if (a.Wo == 64) dadd_launch({"conv3x3_halo_kernel<64, false, false>", flop, bytes}, conv3x3_halo_kernel<64, false>, grid, dim3(512), SMEM_BYTES, s, a);
+    else if (a.Wo == 32) dadd_launch({"conv3x3_halo_kernel<32, false, false>", flop, bytes}, conv3x3_halo_kernel<32, false>, grid, dim3(512), SMEM_BYTES, s, a);
+    else dadd_launch({"conv3x3_halo_kernel<16, false, false>", flop, bytes}, conv3x3_halo_kernel<16, false>, grid, dim3(512), SMEM_BYTES, s, a);
   }
   DADD_LAUNCH_CHECK();
   return DADD_OK;

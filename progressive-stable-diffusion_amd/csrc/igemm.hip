@@ -353,12 +353,18 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C1 = d->C1; a.C2 = d->C2;
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
-  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK | DADD_EPI_GNSTAT | DADD_EPI_LNSTAT);
+  a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK | DADD_EPI_GNSTAT | DADD_EPI_LNSTAT |
+                        DADD_PRE_GN | DADD_PRE_GN_SILU);
   a.gn_ws = d->gn_ws;
   a.gn_nchunk = d->gn_nchunk;
   a.gn_cg = d->gn_cg;   // epilogue bits + the persistent-ring request
   a.ln_c1 = d->ln_c1;
   a.ln_eps = d->ln_eps;
+  a.gni_ws = d->gn_in_ws;
+  a.gni_gamma = d->gn_in_gamma;
+  a.gni_beta = d->gn_in_beta;
+  a.gni_nchunk = d->gn_in_nchunk;
+  a.gni_eps = d->gn_in_eps;
   a.ln_stats_out = d->ln_stats_out;
   a.ln_stats_in = (a.flags & DADD_EPI_LNFOLD) ? d->ln_stats_in : nullptr;
   a.ln_parts_in = d->ln_parts_in;
@@ -486,6 +492,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                      (nsplit == 1 || a.counters != nullptr) && !(a.flags & DADD_EPI_GNSTAT),
                  "igemm: LayerNorm row partials need ln_stats_out, N %% (tile_n/2) == 0, ln_parts_out == N / (tile_n/2) = %d, "
                  "no GEGLU and no finish-kernel split-K", a.N / wn_cols);
+  }
+  if (a.flags & DADD_PRE_GN) {
+    DADD_REQUIRE(halo && !(d->flags & DADD_TUNE_SHALLOW) && a.C2 == 0 && Cin <= 1024 && Cin % 32 == 0 && a.gni_ws &&
+                     a.gni_gamma && a.gni_beta && a.gni_nchunk >= 1 && a.gni_nchunk <= 256 && a.gni_eps > 0.f,
+                 "igemm: GroupNorm on the way in needs the 3x3 halo kernel (stride 1, 64/32/16-wide map, 128x160 tiles), one "
+                 "source with Cin <= 1024, the chunk partials (<= 256 chunks), gamma, beta and eps");
+  } else {
+    DADD_REQUIRE(!(a.flags & DADD_PRE_GN_SILU), "igemm: DADD_PRE_GN_SILU without DADD_PRE_GN");
   }
   if (halo) {
     if (d->flags & DADD_TUNE_SHALLOW) a.flags |= DADD_TUNE_SHALLOW;   // A/B: the two-MFMA-waves-per-SIMD build

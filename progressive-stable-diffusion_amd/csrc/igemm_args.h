@@ -19,6 +19,11 @@ struct IgemmArgs {
   float* ln_stats_out;        // DADD_EPI_LNSTAT: row partials of the OUTPUT, [N / WN][M][2] (WN = columns per MFMA wave)
   const float* ln_stats_in;   // DADD_EPI_LNFOLD with the statistics of x supplied by its producer: [ln_parts_in][M][2]
   int ln_parts_in;
+  const float* gni_ws;        // DADD_PRE_GN: chunk partials of the input [B][gni_nchunk][32][2], affine, eps
+  const float* gni_gamma;
+  const float* gni_beta;
+  int gni_nchunk;
+  float gni_eps;
   int B, Hi, Wi, C1, C2, Ho, Wo, N;
   int taps, stride, ups, pad;
   int ldo, ldr, ld_rowvec;

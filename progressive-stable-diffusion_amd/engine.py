@@ -87,6 +87,10 @@ def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return w16, w16.double().sum(dim=1).float(), bias.float()
 
 
+# GroupNorm (+ SiLU) applied inside the consuming 3x3 conv (DADD_PRE_GN, csrc/conv_halo.hip GNIN): the halo is normalised
+# in LDS by the loader waves; needs the producer's chunk partials, one source, <= 1024 input channels, the halo kernel
+GN_IN_CONV = True
+
 # conv3x3_halo_kernel with two MFMA waves per SIMD (csrc/conv_halo.hip, DUO): measured equal to the one-wave build
 # (profiles/r02_zn_halo_duo_ab.txt), so off; True is the A/B switch
 HALO_DUO = False
@@ -262,8 +266,9 @@ class _Plan:
     # ---- recorded building blocks -----------------------------------------------------------
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
              stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5, gn_stats=False, ln_stats=False,
-             ln_stats_in=None):
-        """``ln_stats``: the output feeds a LayerNorm whose consumer is a folded linear — have the epilogue write the row
+             ln_stats_in=None, gn_in=None):
+        """``gn_in`` = (partials, nchunk, gamma, beta, eps, silu): GroupNorm of ``x`` on the way in (``gn_in_conv_ok``).
+        ``ln_stats``: the output feeds a LayerNorm whose consumer is a folded linear — have the epilogue write the row
         partials (DADD_EPI_LNSTAT) where the launch allows (plain linear, one K pass, whole wave column blocks); they
         are found again through ``self.ln_partials``.  ``ln_stats_in``: such partials of ``x`` for this folded linear.
         ``gn_stats``: the output feeds a GroupNorm — have the epilogue write its chunk partials (DADD_EPI_GNSTAT)
@@ -309,6 +314,9 @@ class _Plan:
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | (L.EPI_LNFOLD if ln_c1 is not None else 0) | tune
         kw = dict(ln_c1=ln_c1, ln_eps=ln_eps) if ln_c1 is not None else {}
+        if gn_in is not None:
+            f |= L.PRE_GN | (L.PRE_GN_SILU if gn_in[5] else 0)
+            kw["gn_in"] = tuple(gn_in[:5])
         if ln_c1 is not None and ln_stats_in is not None:
             kw["ln_stats_in"] = ln_stats_in
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
@@ -316,6 +324,25 @@ class _Plan:
                  tile_n=tile_n, tile_m=tile_m, counters=self.sk_counters if sk > 1 else None, **kw, **gkw)  # None: finish kernel
         self.pool.put(partial)
         return out
+
+    def gn_in_conv_ok(self, x, x2, w, out_shape, residual) -> Optional[Tuple]:
+        """(partials, chunks) of ``x`` if the 3x3 conv (x -> out_shape, weights w) can apply the GroupNorm itself: the conv
+        must land on the halo kernel (csrc/igemm.hip: stride 1 / pad 1, 64-, 32- or 16-wide square map in whole 128-pixel
+        tiles, 128x160 LDS-DMA tiles, no persistent ring) and ``x`` must be a single source of <= 1024 channels whose
+        producer wrote <= 128 chunk partials."""
+        if not GN_IN_CONV or x2 is not None or x.shape[-1] > 1024 or x.shape[-1] % 64:
+            return None
+        part = self.gn_partials.get(x.data_ptr())
+        if part is None or part[1] > 128:
+            return None
+        b, h, w_, _ = x.shape
+        n, m = w.shape[0], out_shape[0] * out_shape[1] * out_shape[2]
+        if tuple(out_shape[1:3]) != (h, w_) or h != w_ or w_ not in (16, 32, 64) or (h * w_) % 128:
+            return None
+        tile_m, tile_n, _, tune = plan_tiling(m, n, w.shape[1], 9, False, residual is not None, 0, 1)
+        if tile_m != 128 or tile_n != 160 or (tune & (L.TUNE_NODMA | L.TUNE_PERSIST)) or HALO_DUO:
+            return None
+        return part
 
     def gn(self, x1, x2, gamma, beta, eps, silu):
         c = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
@@ -440,21 +467,34 @@ class UNetPlan(_Plan):
         cin = x.shape[-1] + (0 if skip is None else skip.shape[-1])
         cout = self.sd[self.prefix + name + ".conv1.weight"].shape[0]
         off = self.temb_off[name]
-        g1 = self.gn(x, skip, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1)
-        h1 = self.conv(g1, self.w(name + ".conv1.weight"), (b, h, w_, cout),
-                       bias=self.f(name + ".conv1.bias"), rowvec=self.temb_rows[:, off:off + cout], gn_stats=True)
-        self.pool.put(g1)
-        g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1)
-        self.pool.put(h1)
+        w1 = self.w(name + ".conv1.weight")
+        p1 = self.gn_in_conv_ok(x, skip, w1, (b, h, w_, cout), None)
+        if p1 is not None:           # norm1 + SiLU inside conv1
+            h1 = self.conv(x, w1, (b, h, w_, cout), bias=self.f(name + ".conv1.bias"),
+                           rowvec=self.temb_rows[:, off:off + cout], gn_stats=True,
+                           gn_in=(p1[0], p1[1], self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1))
+        else:
+            g1 = self.gn(x, skip, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1)
+            h1 = self.conv(g1, w1, (b, h, w_, cout), bias=self.f(name + ".conv1.bias"),
+                           rowvec=self.temb_rows[:, off:off + cout], gn_stats=True)
+            self.pool.put(g1)
         if cin != cout:
             res = self.conv(x, self.w(name + ".conv_shortcut.weight"), (b, h, w_, cout), x2=skip,
                             bias=self.f(name + ".conv_shortcut.bias"), taps=1, pad=0)
         else:
             assert skip is None
             res = x
-        out = self.conv(g2, self.w(name + ".conv2.weight"), (b, h, w_, cout),
-                        bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True)
-        self.pool.put(g2)
+        w2 = self.w(name + ".conv2.weight")
+        p2 = self.gn_in_conv_ok(h1, None, w2, (b, h, w_, cout), res)
+        if p2 is not None:           # norm2 + SiLU inside conv2
+            out = self.conv(h1, w2, (b, h, w_, cout), bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True,
+                            gn_in=(p2[0], p2[1], self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1))
+            self.pool.put(h1)
+        else:
+            g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1)
+            self.pool.put(h1)
+            out = self.conv(g2, w2, (b, h, w_, cout), bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True)
+            self.pool.put(g2)
         if res is not x:
             self.pool.put(res)
         return out

@@ -18,6 +18,7 @@ SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "attn2_fused.hip", "no
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
 EPI_LNFOLD, EPI_QUICKGELU, EPI_GELU, EPI_SIGMOID, EPI_GNSTAT, EPI_LNSTAT = 128, 256, 512, 1024, 2048, 4096
+PRE_GN, PRE_GN_SILU = 8192, 16384
 TUNE_SHALLOW, TUNE_NODMA, TUNE_PERSIST = 16, 32, 64
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
 GN_MAX_CHUNKS = 256
@@ -31,7 +32,8 @@ class IgemmDesc(C.Structure):
                [(n, i32) for n in ("B", "Hi", "Wi", "C1", "C2", "Ho", "Wo", "N", "taps", "stride",
                                    "ups", "pad", "ldo", "ldr", "ld_rowvec", "splitk", "flags",
                                    "tile_n", "tile_m")] + [("counters", vp), ("ln_c1", vp), ("ln_eps", f32), ("gn_ws", vp), ("gn_nchunk", i32), ("gn_cg", i32),
-                                                           ("ln_stats_out", vp), ("ln_stats_in", vp), ("ln_parts_out", i32), ("ln_parts_in", i32)]
+                                                           ("ln_stats_out", vp), ("ln_stats_in", vp), ("ln_parts_out", i32), ("ln_parts_in", i32),
+                                                           ("gn_in_ws", vp), ("gn_in_gamma", vp), ("gn_in_beta", vp), ("gn_in_nchunk", i32), ("gn_in_eps", f32)]
 
 
 # name -> (restype, argtypes); every symbol include/dadd_hip.h declares

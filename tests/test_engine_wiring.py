@@ -162,6 +162,35 @@ def test_unet_plan_fused_attn2_with_norm2_folded(unet_sd, monkeypatch):
         assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item()), lam
 
 
+def test_unet_plan_groupnorm_inside_conv(unet_sd, monkeypatch):
+    """DADD_PRE_GN: where a 3x3 conv of a 16/32/64-wide map reads a single source whose producer wrote the GroupNorm
+    partials, the conv applies norm + SiLU itself (no groupnorm op, no normalised copy); switching the policy off
+    brings the groupnorm ops back and both plans give the oracle's result."""
+    from progressive_stable_diffusion_amd import lib as L
+    torch.manual_seed(6)
+    b, s = 1, 16
+    x, cond = torch.randn(b, 4, s, s), torch.randn(b, 48, 768) * 0.5
+    t = torch.tensor([400])
+    with torch.no_grad():
+        ref = unet_forward(unet_sd, x, t, cond, delta_scale=3.0)
+    counts = {}
+    monkeypatch.setattr(E, "GN_FUSED_MAX_BYTES", 0)          # (small maps: keep the partials path instead of the LDS GroupNorm)
+    for on in (True, False):
+        monkeypatch.setattr(E, "GN_IN_CONV", on)
+        plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+        names = [getattr(fn, "__name__", "") for fn, _, _ in plan.ops]
+        n_in = sum(1 for fn, _, k in plan.ops if k.get("gn_in") is not None)
+        counts[on] = (names.count("groupnorm"), n_in)
+        for fn, _, k in plan.ops:
+            if k.get("gn_in") is not None:
+                assert k["flags"] & L.PRE_GN and k["flags"] & L.PRE_GN_SILU and k["taps"] == 9 and k.get("x2") is None
+        with torch.no_grad():
+            got = plan.forward(x, t, cond, lam=3.0)
+        assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item()), on
+    assert counts[True][1] >= 3 and counts[False][1] == 0
+    assert counts[False][0] - counts[True][0] == counts[True][1]      # one groupnorm op less per conv that normalises
+
+
 def test_unet_plan_baseline_mode(full_sd):
     torch.manual_seed(2)
     sd = full_sd

@@ -354,6 +354,51 @@ def test_conv3x3_halo_kernel(hip, b, h, c1, c2, n, splitk):
     assert torch.equal(o3.cpu(), o1.cpu())
 
 
+@pytest.mark.parametrize("b,h,c,n,silu", [(2, 64, 320, 320, 1), (2, 32, 640, 320, 1), (3, 16, 1024, 160, 0), (1, 64, 64, 160, 1)])
+def test_conv3x3_halo_groupnorm_on_the_way_in(hip, b, h, c, n, silu):
+    """DADD_PRE_GN: the halo conv normalises (+ SiLU) its input in LDS from the producer's chunk partials.  Against
+    groupnorm (from the same partials) -> conv as two launches: same rounding points, so a tight tolerance; image
+    borders (the padding must be zeros of the NORMALISED tensor), 1 / 5 / 10 / 16 channel chunks, all three widths,
+    bias + time row + residual epilogue with the GroupNorm statistics of the OUTPUT on top; contract errors."""
+    from progressive_stable_diffusion_amd import lib as L
+    x = (rnd((b, h, h, c), 86).float() * 1.7 + 0.6).to(F16)
+    k = 9 * c
+    w = rnd((n, k), 87, 1 / math.sqrt(k))
+    bias, rowvec, res = rnd((n,), 88, 0.1, F32), rnd((b, n), 89, 0.3, F32), rnd((b, h, h, n), 90)
+    gamma, beta = rnd((c,), 91, 0.2, F32) + 1.0, rnd((c,), 92, 0.2, F32)
+    nch = max(1, min(128, h * h // 64))
+    xc = x.float().reshape(b, nch, -1, 32, c // 32)
+    part = torch.stack([xc.sum(dim=(2, 4)), (xc * xc).sum(dim=(2, 4))], dim=-1).contiguous()     # [b][nch][32][2]
+    ws = dev(hip, part.reshape(-1))
+    xd, wd = dev(hip, x), dev(hip, w)
+    # two launches
+    xn = hip.zeros((b, h, h, c), F16)
+    hip.groupnorm(xd, None, dev(hip, gamma), dev(hip, beta), xn, ws, 32, 1e-5, silu, ws_chunks=nch)
+    o_ref = hip.zeros((b, h, h, n), F16)
+    hip.igemm(xn, wd, o_ref, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=9, pad=1,
+              flags=7, tile_m=128, tile_n=160)
+    # one launch, with the statistics of the output as well
+    nch_o = h * h // 64
+    ws_o = hip.zeros((b * nch_o * 64,), F32)
+    o = hip.zeros((b, h, h, n), F16)
+    fl = 7 | L.PRE_GN | (L.PRE_GN_SILU if silu else 0) | (L.EPI_GNSTAT if n == 320 else 0)
+    kw = dict(gn_ws=ws_o, gn_nchunk=nch_o) if n == 320 else {}
+    hip.igemm(xd, wd, o, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=9, pad=1, flags=fl,
+              tile_m=128, tile_n=160, gn_in=(ws, nch, dev(hip, gamma), dev(hip, beta), 1e-5), **kw)
+    hip.synchronize()
+    close(o, o_ref.float().cpu(), 2e-3, 1e-3, f"conv with GroupNorm on the way in {b}x{h}x{h}x{c}->{n}")
+    o2 = hip.zeros((b, h, h, n), F16)
+    hip.igemm(xd, wd, o2, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=9, pad=1, flags=fl,
+              tile_m=128, tile_n=160, gn_in=(ws, nch, dev(hip, gamma), dev(hip, beta), 1e-5), **kw)
+    hip.synchronize()
+    assert torch.equal(o2.cpu(), o.cpu())
+    with pytest.raises(ValueError):           # not a halo conv: a 1x1
+        hip.igemm(xd, dev(hip, rnd((n, c), 5)), o, flags=L.PRE_GN, gn_in=(ws, nch, dev(hip, gamma), dev(hip, beta), 1e-5))
+    with pytest.raises(ValueError):           # two sources
+        hip.igemm(xd, dev(hip, rnd((n, 18 * c), 6)), o, x2=xd, taps=9, pad=1, flags=L.PRE_GN, tile_m=128, tile_n=160,
+                  gn_in=(ws, nch, dev(hip, gamma), dev(hip, beta), 1e-5))
+
+
 def test_igemm_geglu(hip):
     from progressive_stable_diffusion_amd.engine import geglu_interleave
     m, c = 300, 320

@@ -115,8 +115,13 @@ class TorchRefBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None):
         self.launches += 1
+        if gn_in is not None:           # PRE_GN: GroupNorm (+ SiLU) of x from its chunk partials, rounded to fp16 like gn_apply
+            ws_in, nch_in, gam, bet, eps_in = gn_in
+            xn = torch.empty_like(x)
+            self.groupnorm(x, None, gam, bet, xn, ws_in, 32, eps_in, 1 if flags & 16384 else 0, ws_chunks=nch_in)
+            x = xn
         xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
         b, hi, wi, cin = xin.shape
         n = w.shape[0]
