@@ -46,7 +46,8 @@ extern "C" {
                                 gn_in_ws its chunk partials [B][gn_in_nchunk][32][2] (a producer's DADD_EPI_GNSTAT), gn_in_gamma /
                                 gn_in_beta the affine; the 3x3 halo kernel normalises the halo in LDS (its loader waves, one
                                 16-byte piece per lane and tap) — no GroupNorm launch, no normalised copy.  3x3 / stride 1 on
-                                64-, 32- or 16-wide maps with 128x160 tiles, one source, Cin <= 1024 */
+                                64-, 32- or 16-wide maps with 128x160 tiles, one source, Cin <= 1152 / 2048 / 2432 (what fits beside the
+                                halo in LDS) */
 #define DADD_PRE_GN_SILU 16384 /* ... followed by SiLU (ResnetBlock2D.norm1/2 + nonlinearity) */
 #define DADD_EPI_GNSTAT 2048 /* the epilogue also writes the GroupNorm chunk partials of its OUTPUT (32 groups) into
                                gn_ws [B][gn_nchunk][32][2] (sum, sum of squares per row block of tile_m/2 rows): the

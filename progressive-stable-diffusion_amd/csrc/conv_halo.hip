@@ -56,6 +56,16 @@ constexpr int SMEM_BYTES = GN_OFF + 4 * 1024;
 constexpr int SMEM_BYTES_GNIN = GN_OFF + 8 * 1024;  // DADD_PRE_GN: scale / shift of <= 1024 input channels (the whole 160 KB)
 constexpr bool DO_LOAD = DADD_IGEMM_EXP != 5 && DADD_IGEMM_EXP != 6;
 
+// DADD_PRE_GN: where the (scale, shift) pair of input channel `ch` lives.  Channels 0..1023 in the 8 KB behind the dump
+// area; the rest in the tail of the second halo buffer that the narrower maps never fill (their dead pieces go to the
+// dump area): 128 more channels at W = 64, 1024 at W = 32, 1408 at W = 16.
+template <int WT>
+constexpr int gn_tab_extra() { return (HALO_BYTES - (((BM / WT + 2) * (WT + 2) + 7) / 8) * 1024) / 8; }
+template <int WT>
+__device__ __forceinline__ int gn_tab_off(int ch) {
+  return ch < 1024 ? GN_OFF + ch * 8 : W_RING + 2 * HALO_BYTES - gn_tab_extra<WT>() * 8 + (ch - 1024) * 8;
+}
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
       const int px = (SL * 4 + wave) * 8 + lrow;
       const int ch0 = cp * BK + (lch ^ (px & 7)) * 8;                 // first of this lane's eight input channels
       const h8 v = *reinterpret_cast<const h8*>(ptr);
-      const f4* tb = reinterpret_cast<const f4*>(smem + GN_OFF) + ch0 / 2;   // table [Cin][2] floats: (scale, shift)
+      const f4* tb = reinterpret_cast<const f4*>(smem + gn_tab_off<WT>(ch0));   // (scale, shift) of eight channels
       const f4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
       const float sc[8] = {t0[0], t0[2], t1[0], t1[2], t2[0], t2[2], t3[0], t3[2]};
       const float sh[8] = {t0[1], t0[3], t1[1], t1[3], t2[1], t2[3], t3[1], t3[3]};
@@ -381,7 +391,6 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
   if constexpr (GNIN) {
     // mean / rstd of this wave's eight groups from the chunk partials (order and precision of gn_apply_kernel), then
     // scale / shift of their channels into the LDS table; the loader waves read it after the barrier below
-    float* tab = reinterpret_cast<float*>(smem + GN_OFF);
     const int cg = Cin >> 5;
     const int g = wave * 8 + (lane >> 3), sub = lane & 7;
     double a = 0.0, q = 0.0;
@@ -413,8 +422,7 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
     for (int cc = sub; cc < cg; cc += 8) {
       const int ch = g * cg + cc;
       const float sc = rstd_f * p.gni_gamma[ch];
-      tab[2 * ch] = sc;
-      tab[2 * ch + 1] = p.gni_beta[ch] - mean_f * sc;
+      *reinterpret_cast<dadd_f2*>(smem + gn_tab_off<WT>(ch)) = dadd_f2{sc, p.gni_beta[ch] - mean_f * sc};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -511,6 +519,11 @@ int dadd_init_conv_halo() {
   if (rc == DADD_OK) rc = set_attr_halo<32, false, true>();
   if (rc == DADD_OK) rc = set_attr_halo<16, false, true>();
   return rc;
+}
+
+// DADD_PRE_GN: input channels whose (scale, shift) fit in LDS for a map of width Wo
+int dadd_conv_halo_gn_channels(int Wo) {
+  return 1024 + (Wo == 64 ? gn_tab_extra<64>() : (Wo == 32 ? gn_tab_extra<32>() : gn_tab_extra<16>()));
 }
 
 // Shapes this kernel takes (everything else stays on the implicit GEMM).

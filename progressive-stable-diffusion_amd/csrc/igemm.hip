@@ -494,10 +494,11 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                  "no GEGLU and no finish-kernel split-K", a.N / wn_cols);
   }
   if (a.flags & DADD_PRE_GN) {
-    DADD_REQUIRE(halo && !(d->flags & DADD_TUNE_SHALLOW) && a.C2 == 0 && Cin <= 1024 && Cin % 32 == 0 && a.gni_ws &&
+    DADD_REQUIRE(halo && !(d->flags & DADD_TUNE_SHALLOW) && a.C2 == 0 && Cin <= dadd_conv_halo_gn_channels(a.Wo) &&
+                     Cin % 32 == 0 && a.gni_ws &&
                      a.gni_gamma && a.gni_beta && a.gni_nchunk >= 1 && a.gni_nchunk <= 256 && a.gni_eps > 0.f,
                  "igemm: GroupNorm on the way in needs the 3x3 halo kernel (stride 1, 64/32/16-wide map, 128x160 tiles), one "
-                 "source with Cin <= 1024, the chunk partials (<= 256 chunks), gamma, beta and eps");
+                 "source with Cin <= 1152 / 2048 / 2432 (W = 64 / 32 / 16), the chunk partials (<= 256 chunks), gamma, beta and eps");
   } else {
     DADD_REQUIRE(!(a.flags & DADD_PRE_GN_SILU), "igemm: DADD_PRE_GN_SILU without DADD_PRE_GN");
   }

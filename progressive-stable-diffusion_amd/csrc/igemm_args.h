@@ -115,4 +115,5 @@ int dadd_launch_igemm_dma(const IgemmArgs& a, int tile_m, int tile_n, int nsplit
 bool dadd_igemm_dma_persistent(const IgemmArgs& a, int nsplit);
 int dadd_init_conv_halo();
 bool dadd_conv_halo_applicable(const IgemmArgs& a, int tile_n);
+int dadd_conv_halo_gn_channels(int Wo);
 int dadd_launch_conv_halo(const IgemmArgs& a, int nsplit, hipStream_t s);   // a.kps = chunks per K slice

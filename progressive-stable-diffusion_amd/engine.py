@@ -328,9 +328,10 @@ class _Plan:
     def gn_in_conv_ok(self, x, x2, w, out_shape, residual) -> Optional[Tuple]:
         """(partials, chunks) of ``x`` if the 3x3 conv (x -> out_shape, weights w) can apply the GroupNorm itself: the conv
         must land on the halo kernel (csrc/igemm.hip: stride 1 / pad 1, 64-, 32- or 16-wide square map in whole 128-pixel
-        tiles, 128x160 LDS-DMA tiles, no persistent ring) and ``x`` must be a single source of <= 1024 channels whose
+        tiles, 128x160 LDS-DMA tiles, no persistent ring) and ``x`` must be a single source of <= 1152 / 2048 / 2432 channels whose
         producer wrote <= 128 chunk partials."""
-        if not GN_IN_CONV or x2 is not None or x.shape[-1] > 1024 or x.shape[-1] % 64:
+        cmax = {64: 1152, 32: 2048, 16: 2432}.get(x.shape[2], 0)      # (scale, shift) pairs that fit beside the halo in LDS
+        if not GN_IN_CONV or x2 is not None or x.shape[-1] > cmax or x.shape[-1] % 64:
             return None
         part = self.gn_partials.get(x.data_ptr())
         if part is None or part[1] > 128:

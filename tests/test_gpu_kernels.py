@@ -354,7 +354,8 @@ def test_conv3x3_halo_kernel(hip, b, h, c1, c2, n, splitk):
     assert torch.equal(o3.cpu(), o1.cpu())
 
 
-@pytest.mark.parametrize("b,h,c,n,silu", [(2, 64, 320, 320, 1), (2, 32, 640, 320, 1), (3, 16, 1024, 160, 0), (1, 64, 64, 160, 1)])
+@pytest.mark.parametrize("b,h,c,n,silu", [(2, 64, 320, 320, 1), (2, 32, 640, 320, 1), (3, 16, 1024, 160, 0), (1, 64, 64, 160, 1),
+                                          (2, 16, 1280, 320, 1), (1, 32, 2048, 160, 1), (1, 64, 1152, 160, 0)])
 def test_conv3x3_halo_groupnorm_on_the_way_in(hip, b, h, c, n, silu):
     """DADD_PRE_GN: the halo conv normalises (+ SiLU) its input in LDS from the producer's chunk partials.  Against
     groupnorm (from the same partials) -> conv as two launches: same rounding points, so a tight tolerance; image
