@@ -643,7 +643,7 @@ class UNetPlan(_Plan):
                 c = h.shape[-1]
                 h = self.conv(h, self.w(f"down_blocks.{i}.downsamplers.0.conv.weight"),
                               (b, h.shape[1] // 2, h.shape[2] // 2, c),
-                              bias=self.f(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=1)
+                              bias=self.f(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=1, gn_stats=True)
                 skips.append(h)
         hn = self._resnet("mid_block.resnets.0", h)        # h is skips[-1]: keep
         h = hn
