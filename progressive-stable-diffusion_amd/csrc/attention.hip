@@ -45,6 +45,20 @@ __device__ __forceinline__ h8 pack_p(const f4& lo, const f4& hi) {
   return r;
 }
 
+// Maxima as the bare instructions: through fmaxf the compiler first canonicalises every operand that comes out of an
+// MFMA or a cross-lane shuffle (v_max_f32 v, v, v — IEEE maxnum must quiet signalling NaNs): 20 of the ~560 vector
+// instructions per 64-key tile of the VALU-bound d = 40 kernel.  Scores are finite here (masking uses -3e38, not inf).
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 struct FlashArgs {
   const half_t* q;
   const half_t* k;
@@ -240,16 +254,16 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
       // 16 scores -> one maximum in 8 three-input maxima (v_max3_f32), a linear chain the compiler keeps as such
-      float mx = fmaxf(sacc[0][f][0], sacc[0][f][1]);
-      mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[0][f][2]), sacc[0][f][3]);
+      float mx = vmax2(sacc[0][f][0], sacc[0][f][1]);
+      mx = vmax3(mx, sacc[0][f][2], sacc[0][f][3]);
 #pragma unroll
       for (int kf = 1; kf < 4; ++kf) {
-        mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[kf][f][0]), sacc[kf][f][1]);
-        mx = __builtin_fmaxf(__builtin_fmaxf(mx, sacc[kf][f][2]), sacc[kf][f][3]);
+        mx = vmax3(mx, sacc[kf][f][0], sacc[kf][f][1]);
+        mx = vmax3(mx, sacc[kf][f][2], sacc[kf][f][3]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrow[f], mx * p.scale_log2);      // running max in log2 units
+      mx = vmax2(mx, __shfl_xor(mx, 16, 64));
+      mx = vmax2(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = vmax2(mrow[f], mx * p.scale_log2);      // running max in log2 units
       const bool moved = mnew > mrow[f];
       float rs = 0.f;
 #pragma unroll
