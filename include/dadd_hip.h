@@ -115,6 +115,9 @@ typedef struct {
   const float* gn_in_beta;
   int32_t gn_in_nchunk;
   float gn_in_eps;
+  const float* gn_in_ws2;        /* DADD_PRE_GN over the concatenation [x | x2]: the chunk partials of x2 (its own 32 groups over
+                                    C2 channels); needs (C1 + C2) / 32 to be a multiple of C1 / 32 and of C2 / 32 and to divide C1 */
+  int32_t gn_in_nchunk2;
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 

@@ -176,14 +176,18 @@ class HipBackend:
             assert flags & L.EPI_LNFOLD and ln_stats_in.dtype == torch.float32 and ln_stats_in.dim() == 3 \
                 and ln_stats_in.shape[1:] == (b * hi * wi, 2) and ln_stats_in.is_contiguous()
             d.ln_parts_in = ln_stats_in.shape[0]
-        d.gn_in_ws = d.gn_in_gamma = d.gn_in_beta = None
-        d.gn_in_nchunk, d.gn_in_eps = 0, 0.0
-        if gn_in is not None:
-            ws_in, nch_in, gam, bet, eps_in = gn_in
+        d.gn_in_ws = d.gn_in_gamma = d.gn_in_beta = d.gn_in_ws2 = None
+        d.gn_in_nchunk, d.gn_in_eps, d.gn_in_nchunk2 = 0, 0.0, 0
+        if gn_in is not None:       # (partials, chunks, gamma, beta, eps[, partials of x2, chunks of x2])
+            ws_in, nch_in, gam, bet, eps_in = gn_in[:5]
             assert flags & L.PRE_GN and ws_in.dtype == gam.dtype == bet.dtype == torch.float32 \
-                and ws_in.numel() >= b * nch_in * 64 and gam.numel() == c1 and bet.numel() == c1
+                and ws_in.numel() >= b * nch_in * 64 and gam.numel() == c1 + c2 and bet.numel() == c1 + c2
             d.gn_in_ws, d.gn_in_gamma, d.gn_in_beta = _p(ws_in), _p(gam), _p(bet)
             d.gn_in_nchunk, d.gn_in_eps = int(nch_in), float(eps_in)
+            if len(gn_in) > 5:
+                ws2, nch2 = gn_in[5], gn_in[6]
+                assert x2 is not None and ws2.dtype == torch.float32 and ws2.numel() >= b * nch2 * 64
+                d.gn_in_ws2, d.gn_in_nchunk2 = _p(ws2), int(nch2)
         if partial is not None:
             assert partial.numel() >= splitk * b * ho * wo * n
         L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))

@@ -393,22 +393,31 @@ __global__ __launch_bounds__(DUO ? 768 : 512, 1) void conv3x3_halo_kernel(const 
     // scale / shift of their channels into the LDS table; the loader waves read it after the barrier below
     const int cg = Cin >> 5;
     const int g = wave * 8 + (lane >> 3), sub = lane & 7;
+    // Skip-concat input: group g of the concatenation [x | x2] is the union of `r` consecutive groups of ONE source
+    // (the host checked that the group widths nest), whose partials carry that source's own 32-group layout.
+    const bool second = p.C2 > 0 && g * cg >= p.C1;
+    const float* wsp = second ? p.gni_ws2 : p.gni_ws;
+    const int nch = second ? p.gni_nchunk2 : p.gni_nchunk;
+    const int wsrc = (second ? p.C2 : p.C1) >> 5;              // group width of the source
+    const int r = p.C2 > 0 ? cg / wsrc : 1;
+    const int g0 = p.C2 > 0 ? ((second ? g * cg - p.C1 : g * cg) / wsrc) : g;
     double a = 0.0, q = 0.0;
-    for (int k = sub; k < p.gni_nchunk; k += 32) {
-      dadd_f2 v[4];
+    for (int j = 0; j < r; ++j)
+      for (int k = sub; k < nch; k += 32) {
+        dadd_f2 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int kk = min(k + 8 * u, p.gni_nchunk - 1);
-        v[u] = *reinterpret_cast<const dadd_f2*>(p.gni_ws + (((size_t)b * p.gni_nchunk + kk) * 32 + g) * 2);
-      }
+        for (int u = 0; u < 4; ++u) {
+          const int kk = min(k + 8 * u, nch - 1);
+          v[u] = *reinterpret_cast<const dadd_f2*>(wsp + (((size_t)b * nch + kk) * 32 + g0 + j) * 2);
+        }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (k + 8 * u < p.gni_nchunk) {
-          a += (double)v[u][0];
-          q += (double)v[u][1];
+        for (int u = 0; u < 4; ++u) {
+          if (k + 8 * u < nch) {
+            a += (double)v[u][0];
+            q += (double)v[u][1];
+          }
         }
       }
-    }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) {
       a += __shfl_xor(a, o, 64);

@@ -365,6 +365,8 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.gni_beta = d->gn_in_beta;
   a.gni_nchunk = d->gn_in_nchunk;
   a.gni_eps = d->gn_in_eps;
+  a.gni_ws2 = d->gn_in_ws2;
+  a.gni_nchunk2 = d->gn_in_nchunk2;
   a.ln_stats_out = d->ln_stats_out;
   a.ln_stats_in = (a.flags & DADD_EPI_LNFOLD) ? d->ln_stats_in : nullptr;
   a.ln_parts_in = d->ln_parts_in;
@@ -494,11 +496,16 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                  "no GEGLU and no finish-kernel split-K", a.N / wn_cols);
   }
   if (a.flags & DADD_PRE_GN) {
-    DADD_REQUIRE(halo && !(d->flags & DADD_TUNE_SHALLOW) && a.C2 == 0 && Cin <= dadd_conv_halo_gn_channels(a.Wo) &&
+    const int cgc = Cin / 32;      // group width of the (concatenated) input
+    DADD_REQUIRE(a.C2 == 0 || (a.gni_ws2 && a.gni_nchunk2 >= 1 && a.gni_nchunk2 <= 256 && cgc > 0 && a.C1 % 32 == 0 &&
+                               a.C2 % 32 == 0 && cgc % (a.C1 / 32) == 0 && cgc % (a.C2 / 32) == 0 && a.C1 % cgc == 0),
+                 "igemm: GroupNorm over a concatenation needs the partials of both sources and group widths that nest "
+                 "((C1+C2)/32 a multiple of C1/32 and C2/32, dividing C1)");
+    DADD_REQUIRE(halo && !(d->flags & DADD_TUNE_SHALLOW) && Cin <= dadd_conv_halo_gn_channels(a.Wo) &&
                      Cin % 32 == 0 && a.gni_ws &&
                      a.gni_gamma && a.gni_beta && a.gni_nchunk >= 1 && a.gni_nchunk <= 256 && a.gni_eps > 0.f,
-                 "igemm: GroupNorm on the way in needs the 3x3 halo kernel (stride 1, 64/32/16-wide map, 128x160 tiles), one "
-                 "source with Cin <= 1152 / 2048 / 2432 (W = 64 / 32 / 16), the chunk partials (<= 256 chunks), gamma, beta and eps");
+                 "igemm: GroupNorm on the way in needs the 3x3 halo kernel (stride 1, 64/32/16-wide map, 128x160 tiles), "
+                 "Cin <= 1152 / 2048 / 2432 (W = 64 / 32 / 16), the chunk partials (<= 256 chunks), gamma, beta and eps");
   } else {
     DADD_REQUIRE(!(a.flags & DADD_PRE_GN_SILU), "igemm: DADD_PRE_GN_SILU without DADD_PRE_GN");
   }

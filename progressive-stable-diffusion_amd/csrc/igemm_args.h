@@ -24,6 +24,8 @@ struct IgemmArgs {
   const float* gni_beta;
   int gni_nchunk;
   float gni_eps;
+  const float* gni_ws2;       // ... of the second source (skip-concat): its own 32 groups over C2 channels
+  int gni_nchunk2;
   int B, Hi, Wi, C1, C2, Ho, Wo, N;
   int taps, stride, ups, pad;
   int ldo, ldr, ld_rowvec;

@@ -314,9 +314,9 @@ class _Plan:
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | (L.EPI_LNFOLD if ln_c1 is not None else 0) | tune
         kw = dict(ln_c1=ln_c1, ln_eps=ln_eps) if ln_c1 is not None else {}
-        if gn_in is not None:
+        if gn_in is not None:       # (partials, chunks, gamma, beta, eps, silu[, partials of x2, chunks of x2])
             f |= L.PRE_GN | (L.PRE_GN_SILU if gn_in[5] else 0)
-            kw["gn_in"] = tuple(gn_in[:5])
+            kw["gn_in"] = tuple(gn_in[:5]) + tuple(gn_in[6:])
         if ln_c1 is not None and ln_stats_in is not None:
             kw["ln_stats_in"] = ln_stats_in
         self.rec(self.be.igemm, x, w, out, x2=x2, bias=bias, rowvec=rowvec, residual=residual,
@@ -331,11 +331,19 @@ class _Plan:
         tiles, 128x160 LDS-DMA tiles, no persistent ring) and ``x`` must be a single source of <= 1152 / 2048 / 2432 channels whose
         producer wrote <= 128 chunk partials."""
         cmax = {64: 1152, 32: 2048, 16: 2432}.get(x.shape[2], 0)      # (scale, shift) pairs that fit beside the halo in LDS
-        if not GN_IN_CONV or x2 is not None or x.shape[-1] > cmax or x.shape[-1] % 64:
+        cin = x.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        if not GN_IN_CONV or cin > cmax or x.shape[-1] % 64 or cin % 64:
             return None
         part = self.gn_partials.get(x.data_ptr())
         if part is None or part[1] > 128:
             return None
+        if x2 is not None:          # skip-concat: both sources' partials, nesting group widths (DADD_PRE_GN contract)
+            part2 = self.gn_partials.get(x2.data_ptr())
+            c1_, c2_, cgc = x.shape[-1], x2.shape[-1], cin // 32
+            if (part2 is None or part2[1] > 128 or c1_ % 32 or c2_ % 32 or cgc % (c1_ // 32) or cgc % (c2_ // 32)
+                    or c1_ % cgc):
+                return None
+            part = (part[0], part[1], part2[0], part2[1])
         b, h, w_, _ = x.shape
         n, m = w.shape[0], out_shape[0] * out_shape[1] * out_shape[2]
         if tuple(out_shape[1:3]) != (h, w_) or h != w_ or w_ not in (16, 32, 64) or (h * w_) % 128:
@@ -470,10 +478,10 @@ class UNetPlan(_Plan):
         off = self.temb_off[name]
         w1 = self.w(name + ".conv1.weight")
         p1 = self.gn_in_conv_ok(x, skip, w1, (b, h, w_, cout), None)
-        if p1 is not None:           # norm1 + SiLU inside conv1
-            h1 = self.conv(x, w1, (b, h, w_, cout), bias=self.f(name + ".conv1.bias"),
+        if p1 is not None:           # norm1 + SiLU inside conv1 (p1 carries the skip's partials too when there is one)
+            h1 = self.conv(x, w1, (b, h, w_, cout), x2=skip, bias=self.f(name + ".conv1.bias"),
                            rowvec=self.temb_rows[:, off:off + cout], gn_stats=True,
-                           gn_in=(p1[0], p1[1], self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1))
+                           gn_in=(p1[0], p1[1], self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1) + tuple(p1[2:]))
         else:
             g1 = self.gn(x, skip, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1)
             h1 = self.conv(g1, w1, (b, h, w_, cout), bias=self.f(name + ".conv1.bias"),

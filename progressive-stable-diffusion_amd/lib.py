@@ -33,7 +33,8 @@ class IgemmDesc(C.Structure):
                                    "ups", "pad", "ldo", "ldr", "ld_rowvec", "splitk", "flags",
                                    "tile_n", "tile_m")] + [("counters", vp), ("ln_c1", vp), ("ln_eps", f32), ("gn_ws", vp), ("gn_nchunk", i32), ("gn_cg", i32),
                                                            ("ln_stats_out", vp), ("ln_stats_in", vp), ("ln_parts_out", i32), ("ln_parts_in", i32),
-                                                           ("gn_in_ws", vp), ("gn_in_gamma", vp), ("gn_in_beta", vp), ("gn_in_nchunk", i32), ("gn_in_eps", f32)]
+                                                           ("gn_in_ws", vp), ("gn_in_gamma", vp), ("gn_in_beta", vp), ("gn_in_nchunk", i32), ("gn_in_eps", f32),
+                                                           ("gn_in_ws2", vp), ("gn_in_nchunk2", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/dadd_hip.h declares

@@ -183,11 +183,23 @@ def test_unet_plan_groupnorm_inside_conv(unet_sd, monkeypatch):
         counts[on] = (names.count("groupnorm"), n_in)
         for fn, _, k in plan.ops:
             if k.get("gn_in") is not None:
-                assert k["flags"] & L.PRE_GN and k["flags"] & L.PRE_GN_SILU and k["taps"] == 9 and k.get("x2") is None
+                assert k["flags"] & L.PRE_GN and k["flags"] & L.PRE_GN_SILU and k["taps"] == 9
+                assert (k.get("x2") is not None) == (len(k["gn_in"]) == 7)      # skip-concat: the skip's partials ride along
         with torch.no_grad():
             got = plan.forward(x, t, cond, lam=3.0)
         assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item()), on
     assert counts[True][1] >= 3 and counts[False][1] == 0
+    # skip-concat inputs: both sources need producer partials — at this toy size the 1x1 linears run on 64-column tiles
+    # (no GroupNorm statistics), so plan them on 64x160 tiles as the 512x512 workload does
+    monkeypatch.setattr(E, "GN_IN_CONV", True)
+    real = E.plan_tiling
+    monkeypatch.setattr(E, "plan_tiling", lambda m, n, k, taps, *a, **kw: (64, 160, 1, 0) if taps == 1 and n % 160 == 0 and m % 64 == 0
+                        and not (a and a[0]) else real(m, n, k, taps, *a, **kw))
+    plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    assert any(k.get("gn_in") is not None and k.get("x2") is not None for _, _, k in plan.ops), "a skip-concat conv normalises too"
+    with torch.no_grad():
+        got = plan.forward(x, t, cond, lam=3.0)
+    assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item())
     assert counts[False][0] - counts[True][0] == counts[True][1]      # one groupnorm op less per conv that normalises
 
 

@@ -395,9 +395,46 @@ def test_conv3x3_halo_groupnorm_on_the_way_in(hip, b, h, c, n, silu):
     assert torch.equal(o2.cpu(), o.cpu())
     with pytest.raises(ValueError):           # not a halo conv: a 1x1
         hip.igemm(xd, dev(hip, rnd((n, c), 5)), o, flags=L.PRE_GN, gn_in=(ws, nch, dev(hip, gamma), dev(hip, beta), 1e-5))
-    with pytest.raises(ValueError):           # two sources
-        hip.igemm(xd, dev(hip, rnd((n, 18 * c), 6)), o, x2=xd, taps=9, pad=1, flags=L.PRE_GN, tile_m=128, tile_n=160,
-                  gn_in=(ws, nch, dev(hip, gamma), dev(hip, beta), 1e-5))
+    if 2 * c <= 1152:
+        with pytest.raises(ValueError):       # two sources need the partials of both
+            g2, b2 = dev(hip, torch.cat([gamma, gamma])), dev(hip, torch.cat([beta, beta]))
+            hip.igemm(xd, dev(hip, rnd((n, 18 * c), 6)), o, x2=xd, taps=9, pad=1, flags=L.PRE_GN, tile_m=128, tile_n=160,
+                      gn_in=(ws, nch, g2, b2, 1e-5))
+
+
+@pytest.mark.parametrize("b,h,c1,c2,n", [(2, 64, 320, 320, 320), (1, 32, 640, 640, 160), (2, 16, 1280, 640, 160)])
+def test_conv3x3_halo_groupnorm_over_skip_concat(hip, b, h, c1, c2, n):
+    """DADD_PRE_GN over [x | x2]: each source brings the chunk partials of ITS OWN 32 groups (different chunk counts); the
+    kernel unites them into the groups of the concatenation (widths nest: 20 = 2 x 10, 40 = 2 x 20; 1280 + 640 gives
+    60 = 1.5 x 40 and must be refused).  Against groupnorm over both sources (its own statistics pass) -> conv."""
+    from progressive_stable_diffusion_amd import lib as L
+    x = (rnd((b, h, h, c1), 86).float() * 1.7 + 0.6).to(F16)
+    x2 = (rnd((b, h, h, c2), 93).float() * 0.8 - 0.3).to(F16)
+    k = 9 * (c1 + c2)
+    w = rnd((n, k), 87, 1 / math.sqrt(k))
+    bias = rnd((n,), 88, 0.1, F32)
+    gamma, beta = rnd((c1 + c2,), 91, 0.2, F32) + 1.0, rnd((c1 + c2,), 92, 0.2, F32)
+
+    def partials(t, nch):
+        tc = t.float().reshape(b, nch, -1, 32, t.shape[-1] // 32)
+        return torch.stack([tc.sum(dim=(2, 4)), (tc * tc).sum(dim=(2, 4))], dim=-1).contiguous().reshape(-1)
+    nch1, nch2 = max(1, h * h // 64), max(1, h * h // 128)
+    ws1, ws2 = dev(hip, partials(x, nch1)), dev(hip, partials(x2, nch2))
+    xd, x2d, wd = dev(hip, x), dev(hip, x2), dev(hip, w)
+    o = hip.zeros((b, h, h, n), F16)
+    args = dict(x2=x2d, bias=dev(hip, bias), taps=9, pad=1, flags=1 | L.PRE_GN | L.PRE_GN_SILU, tile_m=128, tile_n=160,
+                gn_in=(ws1, nch1, dev(hip, gamma), dev(hip, beta), 1e-5, ws2, nch2))
+    if (c1 + c2) // 32 % (c1 // 32) or (c1 + c2) // 32 % (c2 // 32) or c1 % ((c1 + c2) // 32):
+        with pytest.raises(ValueError):
+            hip.igemm(xd, wd, o, **args)
+        return
+    hip.igemm(xd, wd, o, **args)
+    xn = hip.zeros((b, h, h, c1 + c2), F16)
+    hip.groupnorm(xd, x2d, dev(hip, gamma), dev(hip, beta), xn, hip.zeros((b * L.GN_MAX_CHUNKS * 64,), F32), 32, 1e-5, 1)
+    o_ref = hip.zeros((b, h, h, n), F16)
+    hip.igemm(xn, wd, o_ref, bias=dev(hip, bias), taps=9, pad=1, flags=1, tile_m=128, tile_n=160)
+    hip.synchronize()
+    close(o, o_ref.float().cpu(), 3e-3, 2e-3, f"conv with GroupNorm over [x | x2] {b}x{h}x{h}x({c1}+{c2})->{n}")
 
 
 def test_igemm_geglu(hip):

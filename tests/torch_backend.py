@@ -118,10 +118,24 @@ class TorchRefBackend:
               ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None):
         self.launches += 1
         if gn_in is not None:           # PRE_GN: GroupNorm (+ SiLU) of x from its chunk partials, rounded to fp16 like gn_apply
-            ws_in, nch_in, gam, bet, eps_in = gn_in
-            xn = torch.empty_like(x)
-            self.groupnorm(x, None, gam, bet, xn, ws_in, 32, eps_in, 1 if flags & 16384 else 0, ws_chunks=nch_in)
-            x = xn
+            ws_in, nch_in, gam, bet, eps_in = gn_in[:5]
+            if len(gn_in) > 5:          # skip-concat: the partials of both sources, each in its own 32-group layout
+                ws2, nch2 = gn_in[5], gn_in[6]
+                bsz, c1_, c2_ = x.shape[0], x.shape[-1], x2.shape[-1]
+                cgc = (c1_ + c2_) // 32
+                s1 = ws_in[: bsz * nch_in * 64].reshape(bsz, nch_in, 32, 2).double().sum(dim=1)
+                s2 = ws2[: bsz * nch2 * 64].reshape(bsz, nch2, 32, 2).double().sum(dim=1)
+                r1, r2 = cgc // (c1_ // 32), cgc // (c2_ // 32)
+                cat = torch.cat([s1.reshape(bsz, 32 // r1, r1, 2).sum(dim=2), s2.reshape(bsz, 32 // r2, r2, 2).sum(dim=2)], dim=1)
+                wsc = cat.float().reshape(bsz, 1, 32, 2).contiguous().reshape(-1)
+                xc = torch.cat([x, x2], dim=-1)
+                xn = torch.empty_like(xc)
+                self.groupnorm(xc, None, gam, bet, xn, wsc, 32, eps_in, 1 if flags & 16384 else 0, ws_chunks=1)
+                x, x2 = xn[..., :c1_].contiguous(), xn[..., c1_:].contiguous()
+            else:
+                xn = torch.empty_like(x)
+                self.groupnorm(x, None, gam, bet, xn, ws_in, 32, eps_in, 1 if flags & 16384 else 0, ws_chunks=nch_in)
+                x = xn
         xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], dim=-1)
         b, hi, wi, cin = xin.shape
         n = w.shape[0]
