@@ -154,14 +154,18 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
   }
 
   // hoisted tile addressing: what this thread loads / stores for every tile
-  int g_off[NL], g_off_c[NL], k_lds[NL], v_lds[NL], t_row[NL];
+  constexpr bool SLIM = DR <= 40;     // d = 40 sits at the 256-VGPR limit of two blocks per CU: one offset array (below)
+  int g_off[SLIM ? 1 : NL], g_off_c[NL], k_lds[NL], v_lds[NL], t_row[NL];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
     const int idx = t + 256 * u;
     const int row = idx / DC, ch = idx - row * DC;
     t_row[u] = (idx < 64 * DC) ? row : 1 << 30;      // rows past the tile never pass the key test
-    g_off[u] = row * p.ld + h * DR + ch * 8;
-    g_off_c[u] = min(row, 63) * p.ld + h * DR + ch * 8;   // in-tile address for every thread (full tiles)
+    // in-tile address for every thread: a thread without a row (row >= 64) gets a clamped address and never stores; for
+    // the rows that exist this IS row * ld, so with SLIM it serves the ragged path too (4 spilled VGPRs less at d = 40;
+    // the larger head dims keep their own array — dropping it there changed the schedule for the worse: d = 80 33 -> 35 us)
+    g_off_c[u] = min(row, 63) * p.ld + h * DR + ch * 8;
+    if constexpr (!SLIM) g_off[u] = row * p.ld + h * DR + ch * 8;
     k_lds[u] = (ch >> 3) * 4096 + kpanel_off(row, ch & 7);
     v_lds[u] = row * VLD + ch * 8;
   }
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
     for (int u = 0; u < NL; ++u) {
       if (t_row[u] < 64) {
         const bool ok = t_row[u] < kmax;
-        *reinterpret_cast<h8*>(Ks + k_lds[u]) = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
-        *reinterpret_cast<h8*>(Vs + v_lds[u]) = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
+        *reinterpret_cast<h8*>(Ks + k_lds[u]) = ok ? *reinterpret_cast<const h8*>(kbase + toff + (SLIM ? g_off_c[u] : g_off[u])) : zero8;
+        *reinterpret_cast<h8*>(Vs + v_lds[u]) = ok ? *reinterpret_cast<const h8*>(vbase + toff + (SLIM ? g_off_c[u] : g_off[u])) : zero8;
       }
     }
   };
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
 #pragma unroll
       for (int u = 0; u < (PREFETCH ? NL : 1); ++u) {
         const bool ok = t_row[u] < kmax;
-        rk[u] = ok ? *reinterpret_cast<const h8*>(kbase + toff + g_off[u]) : zero8;
-        rv[u] = ok ? *reinterpret_cast<const h8*>(vbase + toff + g_off[u]) : zero8;
+        rk[u] = ok ? *reinterpret_cast<const h8*>(kbase + toff + (SLIM ? g_off_c[u] : g_off[u])) : zero8;
+        rv[u] = ok ? *reinterpret_cast<const h8*>(vbase + toff + (SLIM ? g_off_c[u] : g_off[u])) : zero8;
       }
     }
   };

@@ -5,7 +5,9 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "progressive-stable-diffusion_amd", "csrc")
 for f in sys.argv[1:]:
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+    # (the flags of lib.build(): MFMA accumulators stay in VGPRs)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                        "-I" + os.path.join(ROOT, "include"),
                         "-c", os.path.join(CSRC, f), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True)
     cur = {}
