@@ -10,6 +10,7 @@ Weights are seeded random tensors of the SD-1.4 / DADD architecture (no checkpoi
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no torchrun environment: starts that same command itself, as a child process)
 
 Rank 0 prints ONE JSON line.  ``roofline`` is measured live: after the timed region the same UNet
 step is launched eagerly with every implicit-GEMM launch bracketed by HIP events on its own stream
@@ -45,6 +46,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--tiny-clip", action="store_true", help="2-layer CLIP tower (debug only)")
+    p.add_argument("--launch-selftest", action="store_true",
+                   help="ranks only rendezvous (gloo without a GPU), gather one tensor and print a JSON line: the "
+                        "CPU test of the N > 1 launcher")
     p.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                    help="A/B hook: override an engine policy variable (e.g. LN_STATS_FROM_PRODUCER=False); echoed in config")
     return p.parse_args()
@@ -172,12 +176,49 @@ def live_roofline(mod, a, side, lat, dev, n_steps=2):
                              "gbs": round(t["gbs"], 1)} for t in rows[:10]]}
 
 
+def launcher_argv(n_gpus: int, argv, port: int):
+    """The command the driver itself uses for N > 1 (one rank per GPU, RCCL rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(a, argv) -> int:
+    """``bench.py --gpus N`` started as ONE plain process (no torchrun environment): start the N ranks as a CHILD
+    process — before this process has made any GPU call; nothing here touches HIP, and the child is never exec'ed over
+    a process that did — relay its output (rank 0 prints the JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this pool
+    proc = subprocess.run(launcher_argv(a.gpus, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if (proc.returncode or lines) else 1
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a, sys.argv[1:]))
     from progressive_stable_diffusion_amd import distributed as D
     rank, world, local = D.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.launch_selftest:
+        got = D.all_gather_frames(torch.full((1, 3, 1, 1), float(rank)))
+        t = D.max_over_ranks(float(rank))
+        D.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "launch-selftest", "n_gpus": world, "ranks_seen": got[:, 0, 0, 0].tolist(),
+                              "max_over_ranks": t}), flush=True)
+        return
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 

@@ -107,7 +107,8 @@ def ddim_sample(sd, cfg: OracleCfg, target, source, clip_features, sampling_step
                 trace=None, step_noise=None):
     """Whole sampler.  ``init_latents`` (B,4,S,S) replaces the device ``randn`` (:377-385).
 
-    ``trace``: optional list receiving (eps, latents) per step for step-wise parity tests;
+    ``trace``: optional list receiving (eps, latents after the step, latents before it, CFG parts) per step for
+    step-wise (teacher-forced) parity tests;
     ``step_noise`` (steps-1,B,4,S,S) replaces the per-step ``randn_like`` of the eta > 0 branch (:462-466).
     """
     do_cfg = (not cfg.use_routing_gates) and (guidance_scale != 1.0)
@@ -130,9 +131,11 @@ def ddim_sample(sd, cfg: OracleCfg, target, source, clip_features, sampling_step
     for i in range(sampling_steps):
         t_int = int(ts[i])
         t = torch.full((bsz,), t_int, dtype=torch.long)
+        x_in, parts = x, None
         if do_cfg:
             e_c, e_u = unet(cond), unet(uncond)
             eps = e_u + guidance_scale * (e_c - e_u)
+            parts = (e_c, e_u)
         else:
             eps = unet(cond)
         last = i == sampling_steps - 1
@@ -140,8 +143,8 @@ def ddim_sample(sd, cfg: OracleCfg, target, source, clip_features, sampling_step
         if eta != 0.0 and not last:
             noise = torch.randn_like(x) if step_noise is None else step_noise[i].to(x)
         x = ddim_update(x, eps, ac, t_int, None if last else int(ts[i + 1]), last, eta, noise)
-        if trace is not None:
-            trace.append((eps, x.clone()))
+        if trace is not None:       # (eps, x_{t-1}, x_t the step started from, (eps_cond, eps_uncond) under CFG)
+            trace.append((eps, x.clone(), x_in, parts))
     return x
 
 

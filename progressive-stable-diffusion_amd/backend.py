@@ -36,6 +36,7 @@ class HipBackend:
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
         self._desc = L.IgemmDesc()
+        self._capturing = False     # between graph_begin() and graph_end(): no cross-stream waits may be recorded
         with torch.cuda.device(self.device):
             L.check(self.lib.dadd_init())
 
@@ -57,11 +58,23 @@ class HipBackend:
         with self.ctx():
             return torch.zeros(shape, dtype=dtype, device=self.device)
 
+    def _after_producer(self, src: torch.Tensor):
+        """A device tensor handed in from outside was produced (or is still being produced) on torch's CURRENT
+        stream; the backend stream must not read it earlier, and the caching allocator must not hand its block to
+        another current-stream allocation while the backend stream still reads it."""
+        if src.device.type == "cuda" and not self._capturing:
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self.stream:
+                self.stream.wait_stream(cur)
+                src.record_stream(self.stream)
+
     def to_device(self, t: torch.Tensor, dtype=None):
+        self._after_producer(t)
         with self.ctx():
             return t.to(device=self.device, dtype=dtype or t.dtype).contiguous()
 
     def copy_(self, dst: torch.Tensor, src: torch.Tensor):
+        self._after_producer(src)
         with self.ctx():
             dst.copy_(src.reshape(dst.shape))
 
@@ -70,6 +83,8 @@ class HipBackend:
             t.zero_()
 
     def clone(self, t: torch.Tensor):
+        """Copy made on the backend stream; the caller reads it on torch's current stream only after
+        ``release_to_current()`` (or ``synchronize()``)."""
         with self.ctx():
             return t.detach().clone()
 
@@ -291,8 +306,10 @@ class HipBackend:
     # ------------------------------------------------------------------ graphs / profiling
     def graph_begin(self):
         L.check(self.lib.dadd_graph_begin(self.s))
+        self._capturing = True
 
     def graph_end(self):
+        self._capturing = False
         g = C.c_void_p()
         L.check(self.lib.dadd_graph_end(self.s, C.byref(g)))
         return g

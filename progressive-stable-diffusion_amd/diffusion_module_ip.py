@@ -321,9 +321,13 @@ class DiffusionModuleWithIP:
             if missing:
                 raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
         else:                        # load_from_checkpoint: load_state_dict(strict=...) semantics + a report
+            # The inventory is the MODULE's, not the file's: the reference keeps the whole AutoencoderKL (encoder
+            # included) and the CLIP tower as child modules (diffusion_module_ip.py:120-141), so a file without them
+            # fails ``strict=True`` there; with ``strict=False`` they are reported missing and filled from the seed
+            # (``load_report.filled_from_seed``), never silently.
             from . import checkpoint as CK
-            clip_keys = {k: tuple(v.shape) for k, v in state_dict.items() if k.startswith("image_encoder.")}
-            state_dict = CK.reconcile(dict(state_dict), {**shapes, **clip_keys}, strict=_strict, seed=seed,
+            inventory = {**shapes, **W.vae_shapes(encoder=True), **W.clip_shapes(clip_config)}
+            state_dict = CK.reconcile(dict(state_dict), inventory, strict=_strict, seed=seed,
                                       init_kwargs=dict(gates=gates, aoe_delta_scale=getattr(emb.aoe, "delta_scale", 0.1)),
                                       report=_report)
         self.load_report = _report

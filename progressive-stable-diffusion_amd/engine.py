@@ -968,6 +968,22 @@ class DdimLoop:
         self.be.copy_(self.u.params, torch.tensor([float(lam), float(guidance)], dtype=F32))
         self.u.prepare_attn2(lam)
 
+    def sample(self, latents: torch.Tensor, timesteps: torch.Tensor, alphas_cumprod: torch.Tensor, lam: float,
+               do_cfg: bool = False, guidance: float = 1.0, use_graph: bool = True,
+               trace: Optional[list] = None) -> torch.Tensor:
+        """All prepared steps from ``latents`` -> final latents, WITH both stream hand-offs: the backend stream waits
+        for whatever torch's current stream has queued (conditioning caches written by torch ops, the latents), and
+        the current stream waits for the returned tensor.  Callers that drive ``prepare`` / ``run`` by hand owe the
+        same two calls (``be.wait_current()`` before, ``be.release_to_current()`` after)."""
+        be = self.be
+        be.wait_current()
+        self.prepare(timesteps, alphas_cumprod)
+        be.copy_(self.u.lat_in, latents)
+        self.run(lam, do_cfg, guidance, use_graph=use_graph, trace=trace)
+        out = be.clone(self.u.lat_in)
+        be.release_to_current()
+        return out
+
     def _one_step(self, lam: float, do_cfg: bool, guidance: float, keep_eps: bool = False):
         """``keep_eps``: eps of the step stays readable in ``unet.eps_out`` (traces); otherwise, without CFG, conv_out
         applies the DDIM update itself (``dadd_conv_out_ddim_f16``) and eps is never stored."""

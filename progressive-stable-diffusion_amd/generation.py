@@ -92,6 +92,9 @@ def _load_structure_image(image_path: Path, device: torch.device, target_size: i
     display = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float() / 255.0
     if apply_blur:
         display = _apply_gaussian_blur(display[None], blur_kernel_size, blur_sigma)[0]
+        # the reference hands the blurred tensor to CLIPImageProcessor as a PIL image: ToPILImage = mul(255).byte()
+        # (evaluation_pipeline.py:364-369), i.e. truncation to 8 bits before the CLIP preprocessing
+        display = display.mul(255).to(torch.uint8).float() / 255.0
     return PIPE._clip_preprocess(display).to(device)
 
 
@@ -193,7 +196,11 @@ def _sample_padded(module, targets: List[float], sources: List[float], structs: 
     tgt = _pad_batch(torch.tensor(targets, dtype=torch.float32, device=device), plan_batch)
     src = _pad_batch(torch.tensor(sources, dtype=torch.float32, device=device), plan_batch)
     pix = _pad_batch(torch.cat(structs, dim=0), plan_batch)
-    latents = PIPE._ddim_sample_batched(module, tgt, src, pix, device=device, **kw)
+    # the reference draws randn(n, ...) for the n real samples of a batch (data_augment:239, evaluation_pipeline:506):
+    # draw exactly that and pad the LATENTS, so a ragged last batch consumes the generator as the reference does
+    side = kw.pop("latent_side", None) or module.cfg.dataset.image_size // 8
+    noise = torch.randn(n, module.cfg.model.latent_channels, side, side, device=device, dtype=torch.float32)
+    latents = PIPE._ddim_sample_batched(module, tgt, src, pix, device=device, latents=_pad_batch(noise, plan_batch), **kw)
     return PIPE._latents_to_images(module, latents), n
 
 
@@ -246,19 +253,25 @@ def augment_dataset(module, data_root: Path, train_dst: Path, device: torch.devi
     if not jobs:
         return counts
     sink = FrameSink(module.be, plan_batch, size, size, workers=save_workers)
-    for i in range(0, len(jobs), batch_images):
-        targets, sources, structs, paths = [], [], [], []
-        for job in jobs[i:i + batch_images]:
-            struct = _load_structure_image(job["path"], device, size)
-            for tc in job["targets"]:
-                targets.append(float(tc))
-                sources.append(float(job["source_mes"]))
-                structs.append(struct)
-                paths.append(Path(train_dst) / str(tc) / f"{job['stem']}_generated.bmp")
-                counts[tc] += 1
-        frames, n = _sample_padded(module, targets, sources, structs, plan_batch, device,
-                                   sampling_steps=sampling_steps, eta=eta, image_scale=image_scale,
-                                   steer_scale=steer_scale, guidance_scale=guidance_scale, use_graph=use_graph)
-        sink.submit(frames[:n], paths)
-    sink.close()
+    cls_of: Dict[Path, int] = {}
+    try:
+        for i in range(0, len(jobs), batch_images):
+            targets, sources, structs, paths = [], [], [], []
+            for job in jobs[i:i + batch_images]:
+                struct = _load_structure_image(job["path"], device, size)
+                for tc in job["targets"]:
+                    targets.append(float(tc))
+                    sources.append(float(job["source_mes"]))
+                    structs.append(struct)
+                    paths.append(Path(train_dst) / str(tc) / f"{job['stem']}_generated.bmp")
+                    cls_of[paths[-1]] = tc
+            frames, n = _sample_padded(module, targets, sources, structs, plan_batch, device,
+                                       sampling_steps=sampling_steps, eta=eta, image_scale=image_scale,
+                                       steer_scale=steer_scale, guidance_scale=guidance_scale, use_graph=use_graph,
+                                       latent_side=size // 8)
+            sink.submit(frames[:n], paths)
+    finally:            # a sampler error must not leak the writer pool / pinned slots or swallow a writer's exception
+        written = sink.close()
+    for p in written:   # counts = files actually written (resume skips and failed writes are not counted)
+        counts[cls_of[Path(p)]] += 1
     return counts

@@ -194,13 +194,8 @@ def _ddim_sample_ip(module: DiffusionModuleWithIP, target_labels: Tensor, source
     plan.set_cond(embed_cond, 0)
     if do_cfg:
         plan.set_cond(embed_uncond, 1)
-    loop.prepare(timesteps, module.alphas_cumprod)
-    be.copy_(plan.lat_in, latents)
-    loop.run(float(steer_scale) if use_routing_gates else 0.0, do_cfg, float(guidance_scale),
-             use_graph=use_graph, trace=trace)
-    out = be.clone(plan.lat_in)
-    be.release_to_current()
-    return out
+    return loop.sample(latents, timesteps, module.alphas_cumprod, float(steer_scale) if use_routing_gates else 0.0,
+                       do_cfg, float(guidance_scale), use_graph=use_graph, trace=trace)
 
 
 def _ddim_sample_batched(module: DiffusionModuleWithIP, target_labels: Tensor, source_labels: Tensor,

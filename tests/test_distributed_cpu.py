@@ -70,3 +70,26 @@ def test_shard_bounds_and_padding():
     assert n == 0 and loc.tolist() == [3.0] * 4
     assert D.all_gather_frames(torch.ones(2, 3, 1, 1)).shape == (2, 3, 1, 1)   # single process
     assert D.max_over_ranks(3.5) == 3.5
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with no torchrun environment (what the driver's multi-GPU tier runs) must start the
+    two ranks itself — as a child ``python -m torch.distributed.run`` process — and relay rank 0's single JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = bench.launcher_argv(8, ["--gpus", "8", "--steps", "3", "--warmup", "1"], 29511)
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29511"
+    assert argv[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and argv[-7].endswith("bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0.0, 1.0] and rec["max_over_ranks"] == 1.0

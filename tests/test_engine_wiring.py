@@ -272,7 +272,7 @@ def test_sampler_matches_oracle_config1_shape(gates_on, full_sd):
     assert (c_ref - c_got).abs().max().item() < 8e-3
     assert (c_ref[:, :16] - c_got[:, :16]).abs().max().item() < 1e-4      # AOE tokens: fp32 path
     assert len(trace) == 4
-    for (e_g, x_g), (e_r, x_r) in zip(trace, ref_trace):
+    for (e_g, x_g), (e_r, x_r, _, _) in zip(trace, ref_trace):
         if gates_on:   # with CFG the trace holds the conditional branch only
             assert (e_g - e_r).abs().max().item() < 2e-2
         # x0 = (x - s1*eps)/s0 amplifies an eps error by 1/sqrt(abar_999) = 25x at the first step,

@@ -95,3 +95,21 @@ def test_generate_all_and_augment_through_the_engine(tmp_path):
                      "3/img0_0_generated.bmp", "3/img2_0_generated.bmp"]
     assert np.asarray(Image.open(dst / "1" / "img0_0_generated.bmp")).shape == (64, 64, 3)
     assert G.augment_dataset(mod, aug, dst, torch.device("cpu"), batch_images=2, sampling_steps=1, use_graph=False) == {0: 0, 1: 0, 2: 0, 3: 0}
+
+
+def test_blurred_structure_image_is_quantised_like_the_reference(tmp_path):
+    """with ``apply_blur`` the reference converts the blurred float image to PIL (``ToPILImage`` =
+    ``mul(255).byte()``) before CLIPImageProcessor (evaluation_pipeline.py:355-371): the CLIP input is the
+    preprocessing of the 8-bit-truncated blur, not of the float blur."""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    rs = np.random.RandomState(3)
+    Image.fromarray((rs.rand(50, 60, 3) * 255).astype("uint8")).save(tmp_path / "a.bmp")
+    got = G._load_structure_image(tmp_path / "a.bmp", torch.device("cpu"), 64, apply_blur=True, blur_kernel_size=7, blur_sigma=2.0)
+    pil = Image.open(tmp_path / "a.bmp").convert("RGB").resize((64, 64), Image.BILINEAR)
+    disp = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float() / 255.0
+    blur = G._apply_gaussian_blur(disp[None], 7, 2.0)[0]
+    want = PIPE._clip_preprocess(blur.mul(255).to(torch.uint8).float() / 255.0)
+    assert got.shape == (1, 3, 224, 224) and torch.equal(got, want)
+    assert not torch.equal(got, PIPE._clip_preprocess(blur))         # the float blur is a different input
+    plain = G._load_structure_image(tmp_path / "a.bmp", torch.device("cpu"), 64)
+    assert torch.equal(plain, PIPE._clip_preprocess(disp))

@@ -178,6 +178,23 @@ def test_vae_decode_matches_oracle(hip, full_sd):
     assert d.max().item() < 3e-2 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())
 
 
+_ORACLE_RUNS = {}
+
+
+def _oracle_sample(key, sd, ocfg, target, source, feats, steps, lat, **kw):
+    """The oracle's sampler with its per-step trace, run once per ``key`` and shared between the end-to-end test and
+    the teacher-forced per-step test of the same configuration (tens of CPU-seconds each)."""
+    hit = _ORACLE_RUNS.get(key)
+    if hit is None:
+        tr = []
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        with torch.no_grad():
+            z = OS.ddim_sample(sd, ocfg, target, source, feats, steps, lat, trace=tr, **kw)
+        hit = _ORACLE_RUNS[key] = (z, tr, feats)
+    assert torch.equal(hit[2], feats), "the cached oracle run must have seen the same CLIP features"
+    return hit[0], hit[1]
+
+
 @pytest.mark.parametrize("gates_on", [True, False])
 def test_config1_sampler_matches_oracle(full_sd, gates_on):
     """BASELINE config 1: 1 image, 256x256, 10 DDIM steps, 'guidance 3.0' in both readings
@@ -195,7 +212,7 @@ def test_config1_sampler_matches_oracle(full_sd, gates_on):
                                        latents=lat, use_graph=False, **kw)
         img = PIPE._latents_to_images(mod, z)
         feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
-        z_ref = OS.ddim_sample(full_sd, _ocfg(mod), target, source, feats, 10, lat, **kw)
+        z_ref, _ = _oracle_sample(("c1", gates_on), full_sd, _ocfg(mod), target, source, feats, 10, lat, **kw)
         img_ref = OS.latents_to_images(full_sd, _ocfg(mod), z_ref)
     assert torch.equal(z.cpu(), z_eager.cpu()), "hipGraph replay must equal eager launches bit for bit"
     if gates_on:        # no CFG: conv_out applies the DDIM update itself; the traced run keeps eps and a separate update
@@ -211,6 +228,55 @@ def test_config1_sampler_matches_oracle(full_sd, gates_on):
           f"u8 max {int(u8.max())} mean {u8.float().mean():.3f}")
     assert ez < (5e-2 if gates_on else 0.25)
     assert di.max().item() < (3e-2 if gates_on else 0.1) and di.mean().item() < 4e-3
+
+
+@pytest.mark.parametrize("gates_on", [True, False])
+def test_config1_teacher_forced_eps_per_step(full_sd, gates_on):
+    """The test that does NOT amplify: BASELINE config 1, both readings, TEACHER-FORCED — the
+    oracle's x_t of every one of the 10 steps goes into the HIP UNet (the product's ``module(latents, t, cond)`` with the
+    product's own conditioning) and eps is compared step by step: max|eps_hip - eps_oracle| <= 1e-2 * max|eps_oracle|
+    per step and per branch (conditional / unconditional under CFG).  End-of-trajectory latents (the tests above) divide
+    the first error by sqrt(abar_999) = 0.04; this bound is on the kernels themselves.
+    (reference loop: src/pipelines/inference/inference_pipeline_ip.py:423-456)"""
+    from progressive_stable_diffusion_amd import inference_pipeline_ip as PIPE
+    mod = _module(full_sd, 256, 1, **{"model.use_routing_gates": gates_on})
+    target, source = torch.tensor([3.0]), torch.tensor([0.0])
+    pix = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    lat = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1234))
+    kw = dict(steer_scale=3.0) if gates_on else dict(guidance_scale=3.0)
+    with torch.no_grad():
+        feats = mod.image_encoder.get_hidden_states(pix.to(DEV)).cpu()
+        _, tr = _oracle_sample(("c1", gates_on), full_sd, _ocfg(mod), target, source, feats, 10, lat, **kw)
+        cond = PIPE._prepare_conditioning(mod, target.to(DEV), source.to(DEV), pix.to(DEV))
+        uncond = None if gates_on else PIPE._prepare_conditioning(mod, target.to(DEV), source.to(DEV), pix.to(DEV),
+                                                                  zero_aoe=True)
+        PIPE._set_delta_scale_on_processors(mod, 3.0 if gates_on else 0.0)
+        ts = torch.linspace(999, 0, 10, dtype=torch.long, device=DEV)
+        worst = 0.0
+        for i, (eps_ref, _, x_t, parts) in enumerate(tr):
+            t = ts[i].expand(1)
+            refs = [(cond, eps_ref)] if gates_on else [(cond, parts[0]), (uncond, parts[1])]
+            for c, ref in refs:
+                got = mod(x_t.to(DEV), t, c).cpu()
+                rel = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+                worst = max(worst, rel)
+                assert rel < 1e-2, (gates_on, i, int(ts[i]), rel)
+    print(f"config1 teacher-forced gates={gates_on}: worst per-step eps error {worst:.3e} of max|eps|")
+
+
+def test_ddim_timestep_grid_on_device():
+    """``torch.linspace(T-1, 0, steps, dtype=long, device=cuda)`` — how ``_ddim_sample_ip`` builds its grid
+    (src/pipelines/inference/inference_pipeline_ip.py:389-395) — must give SURVEY.md App. C's irregular integer grids on
+    the DEVICE too (the CPU oracle's grid is asserted in tests/test_oracle_golden.py)."""
+    g50 = [999, 978, 958, 937, 917, 897, 876, 856, 835, 815, 795, 774, 754, 733, 713, 693, 672, 652, 632, 611, 591, 570,
+           550, 530, 509, 489, 468, 448, 428, 407, 387, 366, 346, 326, 305, 285, 265, 244, 224, 203, 183, 163, 142, 122,
+           101, 81, 61, 40, 20, 0]
+    g13 = [999, 915, 832, 749, 666, 582, 499, 416, 333, 249, 166, 83, 0]
+    g10 = [999, 888, 777, 666, 555, 444, 333, 222, 111, 0]
+    for steps, want in ((50, g50), (13, g13), (10, g10)):
+        got = torch.linspace(999, 0, steps=steps, dtype=torch.long, device=DEV)
+        assert got.cpu().tolist() == want, steps
+        assert got.cpu().tolist() == OS.ddim_timesteps(1000, steps).tolist()
 
 
 def test_fused_attn2_sampler_matches_oracle(full_sd, monkeypatch):
@@ -375,8 +441,22 @@ def test_config3_sweep_single_plan_and_four_shards(full_sd):
         # the oracle is per-sample independent (as is the reference): five of the 13 labels keep its CPU time ~1 min
         sub = torch.tensor([0, 1, 6, 11, 12])
         torch.set_num_threads(min(os.cpu_count() or 1, 64))
-        z_ref = OS.ddim_sample(full_sd, _ocfg(mod), labels[sub], torch.zeros(5), feats, 10, lat1.repeat(5, 1, 1, 1),
-                               steer_scale=3.0)
+        z_ref, tr = _oracle_sample("c3", full_sd, _ocfg(mod), labels[sub], torch.zeros(5), feats, 10,
+                                   lat1.repeat(5, 1, 1, 1), steer_scale=3.0)
+        # teacher-forced per-step check of the B = 13 plan (the bound that does not amplify): the oracle's x_t of the five
+        # labels it ran go into their rows of the B = 13 batch (samples are independent: the other rows carry label 0's x_t)
+        cond13 = PIPE._prepare_conditioning(mod, labels.to(DEV), torch.zeros(13, device=DEV), pix.to(DEV))
+        PIPE._set_delta_scale_on_processors(mod, 3.0)
+        ts = torch.linspace(999, 0, 10, dtype=torch.long, device=DEV)
+        worst = 0.0
+        for i, (eps_ref, _, x_t, _) in enumerate(tr):
+            x13 = x_t[:1].repeat(13, 1, 1, 1)
+            x13[sub] = x_t
+            got = mod(x13.to(DEV), ts[i].expand(13), cond13).cpu()[sub]
+            rel = (got - eps_ref).abs().max().item() / max(1.0, eps_ref.abs().max().item())
+            worst = max(worst, rel)
+            assert rel < 1e-2, (i, int(ts[i]), rel)
+        print(f"config3 B=13 teacher-forced: worst per-step eps error {worst:.3e} of max|eps|")
         shards, frames = [], []
         for rank in range(4):
             loc, n_valid = D.shard_labels(labels, rank, 4, 4)
@@ -596,17 +676,31 @@ def test_one_graph_serves_a_lambda_sweep(full_sd):
             assert torch.equal(z, z_e), lam
     assert len(loop.graphs) == 1
     assert (outs[3.0] - outs[0.0]).abs().max().item() > 1e-3 and (outs[1.25] - outs[0.0]).abs().max().item() > 1e-3
-    # NaN in the delta rows of every K/V cache: lambda = 0 must not read them
+    # NaN in the delta rows of every K/V cache: lambda = 0 must not read them.  The NaNs are written by torch ops on
+    # torch's CURRENT stream, the loop runs on the backend's stream: ``DdimLoop.sample`` orders the two both ways (the
+    # hand-offs every product path makes); r2's red run drove prepare / run by hand without them and compared a tensor
+    # the backend stream had not finished writing.
     with torch.no_grad():
         PIPE._ddim_sample_ip(mod, target, source, pix, 1, DEV, steer_scale=0.0, latents=lat)     # projects the cond
         for site, _ in loop.u.sites:
             loop.u.kv[site][0][:, :, 32:, :] = float("nan")
         loop.u._a2_dirty = True
-        loop.prepare(torch.linspace(999, 0, 4, dtype=torch.long), mod.alphas_cumprod)
-        loop.be.copy_(loop.u.lat_in, lat.to(DEV))
-        loop.run(0.0)
-        z_nan = loop.be.clone(loop.u.lat_in)
-    assert torch.equal(z_nan, outs[0.0])
+        z_nan = loop.sample(lat.to(DEV), torch.linspace(999, 0, 4, dtype=torch.long), mod.alphas_cumprod, 0.0)
+        torch.cuda.synchronize()
+        assert all(bool(torch.isnan(loop.u.kv[site][0][:, :, 32:, :]).all()) for site, _ in loop.u.sites), \
+            "the NaNs must still be in the delta rows after the run"
+    diff = (z_nan - outs[0.0]).abs()
+    bad = int((~(diff == 0)).sum())          # NaN != 0 counts as different
+    assert bad == 0, (f"{bad} of {diff.numel()} latents differ from the clean lambda=0 run: NaNs in z_nan "
+                      f"{int(torch.isnan(z_nan).sum())}, max |diff| {float(torch.nan_to_num(diff).max()):.3e}, first at "
+                      f"{[tuple(i.tolist()) for i in (diff != 0).nonzero()[:4]]}")
+    # ... and after a lambda = 3 run on the poisoned caches (which DOES read the delta rows -> NaN) the loop recovers:
+    # a clean re-projection + lambda = 0 reproduces the clean result (no stale per-step state survives a run)
+    with torch.no_grad():
+        z_bad = loop.sample(lat.to(DEV), torch.linspace(999, 0, 4, dtype=torch.long), mod.alphas_cumprod, 3.0)
+        assert not torch.equal(z_bad, outs[3.0]), "lambda != 0 reads the (poisoned) delta rows"
+        z_again = PIPE._ddim_sample_ip(mod, target, source, pix, 4, DEV, steer_scale=0.0, latents=lat)
+    assert torch.equal(z_again, outs[0.0])
 
 
 def test_generation_drivers_and_frame_sink_on_device(full_sd, tmp_path):

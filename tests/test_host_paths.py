@@ -27,7 +27,7 @@ TINY_CLIP = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num
 @pytest.fixture(scope="module")
 def full_sd():
     shapes = dict(W.unet_shapes())
-    shapes.update(W.vae_shapes(encoder=False))
+    shapes.update(W.vae_shapes(encoder=True))       # a Lightning file carries the whole AutoencoderKL
     shapes.update(W.conditioning_shapes(clip_hidden=TINY_CLIP["hidden_size"], clip_proj=TINY_CLIP["projection_dim"]))
     return W.init_state_dict(shapes, 0, gates=GATES, warm_start_dis=False)
 
@@ -218,6 +218,17 @@ def test_checkpoint_strictness_and_reports(full_sd, tmp_path):
     assert torch.equal(m._sd[kd], sd[kd.replace("processor.to_k_dis", "to_k")])     # warm start (:308-314)
     with pytest.raises(RuntimeError, match="missing"):
         _load(p, strict=True)
+    # the inventory is the module's, not the file's — a file WITHOUT the CLIP tower or the VAE
+    # encoder (both child modules of the reference's LightningModule) fails strict=True and is reported under strict=False
+    for drop in ("image_encoder.image_encoder.", "vae.vae.encoder."):
+        lacking = {k: v for k, v in sd.items() if not k.startswith(drop)}
+        torch.save(lacking, tmp_path / "lacking.pt")
+        with pytest.raises(RuntimeError, match="missing"):
+            _load(tmp_path / "lacking.pt", strict=True, clip_config=TINY_CLIP)
+        with pytest.warns(RuntimeWarning, match="SEEDED RANDOM"):
+            m2 = _load(tmp_path / "lacking.pt", strict=False, clip_config=TINY_CLIP)
+        miss = m2.load_report.missing
+        assert miss and all(k.startswith(drop) for k in miss) and set(m2.load_report.filled_from_seed) == set(miss)
     bad = dict(sd)
     bad["unet.unet.conv_in.weight"] = torch.zeros(320, 4, 1, 1)
     torch.save(bad, tmp_path / "bad.pt")
