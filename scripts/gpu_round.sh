@@ -2,7 +2,7 @@
 # One gpurun call = one box acquisition (minutes of budget): run the whole GPU checklist in it.
 # A step that TIMES OUT or is KILLED ends the call (no further GPU work on a possibly wedged card);
 # ordinary test failures are logged and the later steps still run.
-# usage: scripts/gpu_round.sh <tag> [steps...]   steps: kernels parity smoke stepprof stepprofvae bench prof pmc
+# usage: scripts/gpu_round.sh <tag> [steps...]   steps: full kernels parity smoke stepprof stepprofvae bench prof pmc
 set -u
 tag=${1:-r01}; shift || true
 steps=${*:-"kernels parity smoke bench prof"}
@@ -20,6 +20,9 @@ run() {  # run <name> <timeout_s> <cmd...>
 python -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1 || { tail -20 "$out/build.log"; exit 1; }
 for s in $steps; do
   case $s in
+    full)    # the driver's exact round-end commands, in its order: run this ONCE as the last GPU action after the last code change
+             run full 1100 python -m pytest tests/ -x -q -m gpu
+             run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     kernels) run kernels 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout=300 ;;
     parity)  run parity 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s --timeout=600 ;;
     smoke)   run smoke 300 python __graft_entry__.py smoke ;;
