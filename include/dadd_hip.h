@@ -230,6 +230,18 @@ int dadd_attn2_fused_f16(const void* x, const void* mcat, const void* vw, const 
                          int ln_parts_in, const float* ln_c1, const float* ln_d, float ln_eps, int B, int HW, int C,
                          void* stream);
 
+/* The tail of one transformer block at a 320-channel site as ONE launch per 64-token row block (csrc/ffn_block.hip):
+ *   out = proj_out( h4 ) + bp + xres,   h4 = ff.net.2( GEGLU( ff.net.0.proj( LayerNorm3(x) ) ) ) + b2 + x
+ * Replaces norm3 / ff.net.0.proj (GEGLU) / ff.net.2 / proj_out of diffusers' BasicTransformerBlock + Transformer2DModel
+ * (the UNet body behind /root/reference/src/models/unet/unet.py:140-144).
+ * x, xres, out: [M][320] fp16 (M = whole samples of HW tokens, HW % 64 == 0);  stream: dadd_ffn_block_bytes() bytes of
+ * pre-swizzled weight pieces in consumption order (engine.pack_ffn_stream);  b1: GEGLU bias in piece order (2560);
+ * gn_ws (optional): GroupNorm chunk partials of `out`, [M/HW][gn_nchunk = HW/32][32][2] fp32 (sums of the rounded values). */
+int dadd_ffn_block_f16(const void* x, const void* stream, const float* ln_g, const float* ln_b, float ln_eps,
+                       const float* b1, const float* b2, const float* bp, const void* xres, void* out, float* gn_ws,
+                       int gn_nchunk, int M, int HW, int C, void* stream_handle);
+int dadd_ffn_block_bytes(void);
+
 /* ---- sampler glue --------------------------------------------------------------------------
  * Sinusoidal timestep features (flip_sin_to_cos, shift 0): out[m][0:dim/2]=cos, [dim/2:]=sin. */
 int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream);

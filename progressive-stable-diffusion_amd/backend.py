@@ -258,6 +258,21 @@ class HipBackend:
         L.check(self.lib.dadd_attn2_fused_f16(_p(x), _p(mcat), _p(vw), _p(bias), _p(residual), _p(out), _p(ln_stats_out),
                                               _p(ln_stats_in), parts, _p(ln_c1), _p(ln_d), float(ln_eps), b, hw, c, self.s))
 
+    def ffn_block(self, x, stream, ln_g, ln_b, b1, b2, bp, xres, out, gn_ws=None, gn_nchunk=0, ln_eps=1e-5):
+        """Transformer-block tail in one launch (csrc/ffn_block.hip): x, xres, out [B,HW,320] fp16; ``stream`` / ``b1``
+        from ``engine.pack_ffn_stream``; ``gn_ws`` [B*gn_nchunk*64] fp32 receives GroupNorm partials of ``out``
+        (chunks of 32 rows)."""
+        b, hw, c = x.shape
+        assert out.shape == x.shape == xres.shape and x.dtype == out.dtype == xres.dtype == torch.float16
+        assert stream.dtype == torch.float16 and stream.numel() * 2 == self.lib.dadd_ffn_block_bytes()
+        assert b1.numel() == 2560 and b2.numel() == c and bp.numel() == c and ln_g.numel() == c and ln_b.numel() == c
+        assert all(t.dtype == torch.float32 for t in (ln_g, ln_b, b1, b2, bp))
+        assert x.is_contiguous() and xres.is_contiguous() and out.is_contiguous()
+        if gn_ws is not None:
+            assert gn_ws.dtype == torch.float32 and gn_ws.numel() >= b * gn_nchunk * 64
+        L.check(self.lib.dadd_ffn_block_f16(_p(x), _p(stream), _p(ln_g), _p(ln_b), float(ln_eps), _p(b1), _p(b2), _p(bp),
+                                            _p(xres), _p(out), _p(gn_ws), int(gn_nchunk), b * hw, hw, c, self.s))
+
     def timestep_features(self, t, out):
         assert t.dtype == torch.int64 and out.dtype == torch.float32
         L.check(self.lib.dadd_timestep_features_f32(_p(t), _p(out), out.shape[0], out.shape[1], self.s))

@@ -11,6 +11,7 @@ int dadd_init_igemm();
 int dadd_init_attention();
 int dadd_init_norm();
 int dadd_init_attn2_fused();
+int dadd_init_ffn_block();
 
 namespace {
 thread_local char g_err[512] = "";
@@ -58,7 +59,8 @@ int dadd_init(void) {
   int rc = dadd_init_igemm();
   if (rc == DADD_OK) rc = dadd_init_attention();
   if (rc == DADD_OK) rc = dadd_init_norm();
-  return rc != DADD_OK ? rc : dadd_init_attn2_fused();
+  if (rc == DADD_OK) rc = dadd_init_attn2_fused();
+  return rc != DADD_OK ? rc : dadd_init_ffn_block();
 }
 
 int dadd_device_info(int device, int64_t out[4]) {

@@ -1,0 +1,486 @@
+// The tail of one transformer block at the C = 320 sites (64x64 maps) as ONE kernel per 64-token row block:
+//
+//     LayerNorm 3 -> GEGLU projection (320 -> 2 x 1280) -> hidden * gelu(gate) -> FF-out (1280 -> 320) + bias + residual
+//                 -> proj_out (1x1 conv 320 -> 320) + bias + the block's outer residual (+ GroupNorm partials of the result)
+//
+// Replaces four launches of diffusers' BasicTransformerBlock / Transformer2DModel tail (``norm3``,
+// ``ff.net.0.proj`` (GEGLU), ``ff.net.2``, ``proj_out``) and the HBM round trip of the (B*N) x 4C GEGLU output (42 MB
+// written and read back per block at B = 4 / 512x512) and of h4.  Rounding points are the ones of the unfused launches:
+// the normalised rows, the GEGLU output, h4 and the result are each rounded to fp16 once.
+//
+// A workgroup owns 64 tokens and ALL channels, so LayerNorm needs no partner and every intermediate stays on the CU:
+//   * the token tile (64 x 320 fp16, 40 KB) is fetched once by LDS-DMA, normalised in LDS, and its MFMA B-fragments then
+//     live in REGISTERS for the whole kernel (80 VGPRs): the steady state reads only weights from LDS;
+//   * the weights (GEGLU 1.6 MB, FF-out 0.8 MB, proj_out 0.2 MB — identical for every workgroup, L2-resident) arrive as
+//     ONE stream of pre-swizzled LDS images ("pieces", packed on the host), moved by four loader waves through a
+//     six-slot ring behind counted s_waitcnt vmcnt and one raw s_barrier per piece; four MFMA waves (one per SIMD)
+//     consume them.  Wave-specialised like igemm_dma.hip;
+//   * per 64 hidden channels: GEMM1 (5 pieces of [128 rows = 2 waves x (16 hid | 16 gate | 16 hid | 16 gate)] x 64 k),
+//     GEGLU in registers, the 64 x 64 tile of G crosses LDS once (the two waves of a row half exchange their hidden
+//     halves), GEMM2 (2 pieces of [160 n] x 64 hidden) accumulates the FF output in registers (80 VGPRs);
+//   * h4 = FF output + bias + residual goes back through the token-tile buffer into the B-fragment registers and the ten
+//     proj_out pieces follow in the same stream.
+// Measured at B = 4 / 64x64 (scripts/ffn_bench.py, profiles/r03_c_ffn_bench.txt): 85 us against 127 us for the three
+// launches it replaces; the stream alone (loaders only) 53 us, the MFMA waves alone 62 us, MFMA waves beside the DMA
+// issue with nothing fetched 80 us — the LDS writes of the DMA lengthen every fragment read of the MFMA waves, whose
+// LDS latency is not covered (one wave per SIMD).  A variant with double-buffered fragments, GEMM2 lagging one chunk
+// (its MFMAs under the GELU arithmetic) and the token tile read from LDS had to give up a ring slot for the registers:
+// its stream alone took 77 us (four pieces in flight instead of five: the stream is latency x bytes-in-flight bound)
+// and the launch 104 us (profiles/r03_d_ffn_bench_v2.txt) — not kept.
+#include "dadd_common.h"
+#include "igemm_args.h"       // xcd_remap
+#include "igemm_epilogue.h"   // dadd_row16_sum
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+constexpr int C = 320, HID = 1280, RB = 64;
+constexpr int KT = C / 64;                                  // 5 K tiles of 64
+constexpr int NCHUNK = HID / 64;                            // 20 chunks of 64 hidden channels
+constexpr int P1_BYTES = 128 * 128;                         // [128 rows][64 k] fp16
+constexpr int P2_BYTES = 160 * 128;                         // [160 rows][64 k] fp16
+constexpr int SLOT = P2_BYTES, NSLOT = 6;
+constexpr int XBUF = RB * C * 2;                            // 40 KB: the token tile; then the G image; then h4
+constexpr int SMEM_BYTES = XBUF + NSLOT * SLOT;             // 160 KB
+constexpr int PPC = KT + 2;                                 // pieces per chunk
+constexpr int NP_FFN = NCHUNK * PPC;                        // 140
+constexpr int NP = NP_FFN + 2 * KT;                         // + proj_out: 150
+constexpr int CHUNK_BYTES = KT * P1_BYTES + 2 * P2_BYTES;   // the stream holds chunk c at c * CHUNK_BYTES: P1 x 5, P2 x 2
+constexpr int STREAM_BYTES = NCHUNK * CHUNK_BYTES + 2 * KT * P2_BYTES;
+constexpr int AHEAD = NSLOT - 1;                            // pieces issued beyond the one being consumed
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct FfnArgs {
+  const half_t* x;        // [M][320] hidden state before norm3 (also the FF residual)
+  const half_t* stream;   // STREAM_BYTES of pre-swizzled pieces (engine.pack_ffn_stream)
+  const float* ln_g;      // norm3 weight / bias
+  const float* ln_b;
+  const float* b1;        // GEGLU bias in piece order: [chunk][wn][u][hid 16 | gate 16]
+  const float* b2;        // ff.net.2 bias [320]
+  const float* bp;        // proj_out bias [320]
+  const half_t* xres;     // [M][320] the transformer block's input (outer residual)
+  half_t* out;            // [M][320]
+  float* gn_ws;           // null, or GroupNorm chunk partials of `out`: [B][gn_nchunk][32][2], one chunk per 32 rows
+  float ln_eps;
+  int M, HW, gn_nchunk;
+};
+
+__device__ __forceinline__ int img_off(int row, int chunk) {   // bytes; 128-byte rows, 16-byte chunks XOR-swizzled
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {        // n is wave-uniform
+  switch (n) {
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    W_(0) W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16)
+    W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25)
+#undef W_
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// Order of the pieces (q = 0 .. 149) = their order in the stream: per chunk P1 x 5, P2 x 2; then proj_out x 10.
+struct PieceCursor {
+  int q, pos;             // piece index; position inside its chunk
+  __device__ __forceinline__ void reset() { q = 0; pos = 0; }
+  __device__ __forceinline__ bool five() const { return q >= NP_FFN || pos >= KT; }          // P2 / P3: five KB per wave
+  __device__ __forceinline__ void next() {
+    ++q;
+    pos = pos + 1 == PPC ? 0 : pos + 1;
+  }
+};
+
+// EXP: 0 = the product; diagnostic builds (scripts/ffn_bench.py, never launched by the engine): 1 = stream only (the
+// MFMA waves keep the barrier protocol but compute nothing), 2 = the loaders' descriptor has zero records (DMA issued,
+// nothing fetched), 3 = no DMA at all (MFMA waves on whatever LDS holds)
+template <int EXP>
+__global__ __launch_bounds__(512, 2) void ffn_block_kernel(const FfnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* const xbuf = smem;
+  char* const ring = smem + XBUF;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wave_all >= 4;
+  const int wave = wave_all & 3;
+  const int m0 = xcd_remap(blockIdx.x, gridDim.x) * RB;
+
+  // ---- the token tile: 40 pieces of 1 KB (8 rows x 128 B), five per wave, all eight waves
+  {
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.M * C * 2, 0x00020000);
+    const int lrow = lane >> 3, lch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int q = wave_all * 5 + i, kt = q >> 3, rb = q & 7;
+      const int row = rb * 8 + lrow;
+      const unsigned vo = (unsigned)(((m0 + row) * C + kt * 64 + (lch ^ ((row >> 1) & 7)) * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lptr_t)(xbuf + kt * 8192 + rb * 1024), 16, vo, 0, 0, 0);
+    }
+  }
+
+  if (loader) {
+    // ---- loader waves: the weight stream through the ring.  Piece q (this wave's quarter: 4 or 5 DMA instructions of
+    // 1 KB) goes to slot q % 6; it is issued right after barrier(q - 5), which every MFMA wave passes only when it has
+    // finished piece q - 6, the slot's previous tenant.
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.stream, 0, EXP == 2 ? 0 : STREAM_BYTES, 0x00020000);
+    const unsigned vo = (unsigned)(wave * 1024 + lane * 16);
+    PieceCursor iss, cur;
+    iss.reset();
+    cur.reset();
+    int iss_slot = 0;
+    unsigned off = 0;
+    auto issue_piece = [&]() {
+      const bool five = iss.five();
+      char* dst = ring + iss_slot * SLOT + wave * 1024;
+      if constexpr (EXP != 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(dst + i * 4096), 16, vo, off + i * 4096, 0, 0);
+        if (five) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(dst + 4 * 4096), 16, vo, off + 4 * 4096, 0, 0);
+      }
+      off += five ? P2_BYTES : P1_BYTES;
+      iss.next();
+      iss_slot = iss_slot + 1 == NSLOT ? 0 : iss_slot + 1;
+    };
+    int ahead = 0;                       // DMA instructions of this wave that belong to pieces after `cur`
+#pragma unroll 1
+    for (int q = 0; q < AHEAD; ++q) {
+      if (q > 0) ahead += iss.five() ? 5 : 4;
+      issue_piece();
+    }
+    if constexpr (EXP == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else wait_vmcnt_dyn(ahead + 4);         // the token tile (older than every piece) has landed
+    __builtin_amdgcn_s_barrier();           // B0: token tile visible
+    __builtin_amdgcn_s_barrier();           // B1: LayerNorm written
+#pragma unroll 1
+    for (int it = 0; it < NP; ++it) {
+      if constexpr (EXP != 3) wait_vmcnt_dyn(ahead);        // piece `it` has landed (this wave's quarter)
+      __builtin_amdgcn_s_barrier();
+      if (iss.q < NP) {
+        ahead += iss.five() ? 5 : 4;
+        issue_piece();
+      }
+      if (it == NP_FFN - 1) __builtin_amdgcn_s_barrier();   // B_mid: G is dead, h4 may overwrite it
+      cur.next();
+      if (cur.q < NP) ahead -= cur.five() ? 5 : 4;
+    }
+    return;
+  }
+
+  // ---- MFMA waves: (wr, wn) = (row half of the 64 tokens, column half of every piece)
+  const int wr = wave >> 1, wn = wave & 1;
+  const int mc = lane & 15, fq = lane >> 4, g = fq;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();             // B0
+
+  // LayerNorm 3 in LDS: four lanes per row, ten 16-byte chunks each; exact two-pass variance; fp16 result in place
+  {
+    const int tid = wave * 64 + lane, row = tid >> 2, q4 = tid & 3;
+    h8 v[10];
+    float s1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int cc = q4 + 4 * u;
+      v[u] = *reinterpret_cast<const h8*>(xbuf + (cc >> 3) * 8192 + img_off(row, cc & 7));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1 += (float)v[u][e];
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64);
+    const float mu = s1 * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 10; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[u][e] - mu;
+        s2 = fmaf(d, d, s2);
+      }
+    s2 += __shfl_xor(s2, 1, 64);
+    s2 += __shfl_xor(s2, 2, 64);
+    const float rstd = rsqrtf(s2 * (1.0f / C) + p.ln_eps);
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int cc = q4 + 4 * u;
+      const f4 g0 = *reinterpret_cast<const f4*>(p.ln_g + cc * 8), g1 = *reinterpret_cast<const f4*>(p.ln_g + cc * 8 + 4);
+      const f4 b0 = *reinterpret_cast<const f4*>(p.ln_b + cc * 8), b1 = *reinterpret_cast<const f4*>(p.ln_b + cc * 8 + 4);
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)fmaf(((float)v[u][e] - mu) * rstd, g0[e], b0[e]);
+        o[e + 4] = (half_t)fmaf(((float)v[u][e + 4] - mu) * rstd, g1[e], b1[e]);
+      }
+      *reinterpret_cast<h8*>(xbuf + (cc >> 3) * 8192 + img_off(row, cc & 7)) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();             // B1
+  if constexpr (EXP == 1) {                 // diagnostic: the stream alone
+#pragma unroll 1
+    for (int it = 0; it < NP + 1; ++it) __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // B fragments of the normalised rows: xf[k step of 32][16-row tile] — in registers for the whole kernel
+  const int xrow = wr * 32 + mc;
+  h8 xf[2 * KT][2];
+  auto load_xf = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2 * KT; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        xf[ks][i] = *reinterpret_cast<const h8*>(xbuf + (ks >> 1) * 8192 + img_off(xrow + i * 16, (ks & 1) * 4 + fq));
+  };
+  load_xf();
+
+  int fa1[2], fa2[2], fg[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    fa1[s] = img_off(wn * 64 + mc, s * 4 + fq);
+    fa2[s] = img_off(wn * 80 + mc, s * 4 + fq);
+    fg[s] = img_off(xrow, s * 4 + fq);
+  }
+  char* const gbuf = xbuf;                  // [64 tokens][64 hidden] fp16 image, 8 KB (the token tile is in registers)
+
+  f4 acc2[2][5][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc2[a][b][c] = f4{0.f, 0.f, 0.f, 0.f};
+
+  int slot = 0;
+  // GEMM1 starts from the GEGLU bias of this wave's rows ([u][hid | gate], this lane's four rows of each tile) instead of
+  // zero; the bias of chunk ch + 1 is fetched while chunk ch computes
+  f4 bnext[4];
+  auto fetch_bias = [&](int ch) {
+    const float* bsrc = p.b1 + ((ch * 2 + wn) * 2) * 32 + g * 4;
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) bnext[tl] = *reinterpret_cast<const f4*>(bsrc + tl * 16);
+  };
+  fetch_bias(0);
+#pragma unroll 1
+  for (int ch = 0; ch < NCHUNK; ++ch) {
+    f4 acc1[4][2];
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl) acc1[tl][0] = acc1[tl][1] = bnext[tl];
+    fetch_bias(ch + 1 < NCHUNK ? ch + 1 : ch);
+    // ---- GEMM1: [h0 g0 h1 g1] x 32 tokens over K = 320
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      const char* pc = ring + slot * SLOT;
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        h8 a[4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) a[tl] = *reinterpret_cast<const h8*>(pc + fa1[s] + tl * 2048);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc1[tl][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tl], xf[kt * 2 + s][i], acc1[tl][i], 0, 0, 0);
+      }
+    }
+    // ---- GEGLU: hidden * gelu(gate), rounded to fp16 once (the unfused epilogue's rounding point), into the G image
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f4 hv = acc1[u * 2][i], gv = acc1[u * 2 + 1][i];
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(hv[r] * dadd_gelu(gv[r]));
+        const int row = xrow + i * 16, j0 = wn * 32 + u * 16 + g * 4;
+        *reinterpret_cast<h4*>(gbuf + img_off(row, j0 >> 3) + (j0 & 7) * 2) = o;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the G writes have reached LDS before the barrier publishes them
+    // ---- GEMM2: FF-out, this wave's 2 x 80 output channels, K = the chunk's 64 hidden channels
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      __builtin_amdgcn_s_barrier();          // (nh == 0: also publishes G)
+      const char* pc = ring + slot * SLOT;
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        h8 gb[2], a[5];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gb[i] = *reinterpret_cast<const h8*>(gbuf + fg[s] + i * 2048);
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl) a[tl] = *reinterpret_cast<const h8*>(pc + fa2[s] + tl * 2048);
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc2[nh][tl][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tl], gb[i], acc2[nh][tl][i], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- h4 = FF output + bias + residual (h3), fp16, back into the token-tile image
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();             // B_mid: every wave is done with G
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int tl = 0; tl < 5; ++tl) {
+      const int n = nh * 160 + wn * 80 + tl * 16 + g * 4;
+      const f4 bias = *reinterpret_cast<const f4*>(p.b2 + n);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = xrow + i * 16;
+        const h4 rv = *reinterpret_cast<const h4*>(p.x + (size_t)(m0 + row) * C + n);
+        const f4 v = acc2[nh][tl][i] + bias;
+        const h4 o = {(half_t)(v[0] + (float)rv[0]), (half_t)(v[1] + (float)rv[1]), (half_t)(v[2] + (float)rv[2]),
+                      (half_t)(v[3] + (float)rv[3])};
+        *reinterpret_cast<h4*>(xbuf + (n >> 6) * 8192 + img_off(row, (n & 63) >> 3) + (n & 7) * 2) = o;
+        acc2[nh][tl][i] = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- proj_out: ten pieces [160 n][64 k] against the h4 fragments
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      if (nh == 0 && kt == 0) load_xf();     // h4 is visible behind this barrier
+      const char* pc = ring + slot * SLOT;
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        h8 a[5];
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl) a[tl] = *reinterpret_cast<const h8*>(pc + fa2[s] + tl * 2048);
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc2[nh][tl][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tl], xf[kt * 2 + s][i], acc2[nh][tl][i], 0, 0, 0);
+      }
+    }
+
+  // ---- out = proj_out + bias + outer residual; GroupNorm partials of the ROUNDED values, one chunk per 32 rows
+  float* scratch = reinterpret_cast<float*>(xbuf + 16384) + wave * 320;     // [160 columns][2] per wave; h4 is dead
+  const int bsmp = m0 / p.HW;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int tl = 0; tl < 5; ++tl) {
+      const int n = nh * 160 + wn * 80 + tl * 16 + g * 4;
+      const f4 bias = *reinterpret_cast<const f4*>(p.bp + n);
+      float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const size_t m = (size_t)(m0 + xrow + i * 16);
+        const h4 rv = *reinterpret_cast<const h4*>(p.xres + m * C + n);
+        const f4 v = acc2[nh][tl][i] + bias;
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (half_t)(v[r] + (float)rv[r]);
+          const float f = (float)o[r];
+          cs[r] += f;
+          cq[r] = fmaf(f, f, cq[r]);
+        }
+        *reinterpret_cast<h4*>(p.out + m * C + n) = o;
+      }
+      if (p.gn_ws) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cs[r] = dadd_row16_sum(cs[r]);
+          cq[r] = dadd_row16_sum(cq[r]);
+        }
+        if (mc == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            scratch[((nh * 5 + tl) * 16 + g * 4 + r) * 2] = cs[r];
+            scratch[((nh * 5 + tl) * 16 + g * 4 + r) * 2 + 1] = cq[r];
+          }
+        }
+      }
+    }
+  if (p.gn_ws) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 16) {                        // 2 x 8 groups of 10 channels in this wave's 2 x 80 columns
+      const int nh = lane >> 3, gl = lane & 7;
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 10; ++c) {
+        a += scratch[(nh * 80 + gl * 10 + c) * 2];
+        q += scratch[(nh * 80 + gl * 10 + c) * 2 + 1];
+      }
+      const int chunk = (m0 - bsmp * p.HW + wr * 32) >> 5;
+      const int grp = nh * 16 + wn * 8 + gl;
+      float* w = p.gn_ws + (((size_t)bsmp * p.gn_nchunk + chunk) * 32 + grp) * 2;
+      w[0] = a;
+      w[1] = q;
+    }
+  }
+#endif
+}
+
+}  // namespace
+
+template <int EXP>
+int ffn_set_attr() {
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_block_kernel<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SMEM_BYTES));
+  return DADD_OK;
+}
+
+int dadd_init_ffn_block() {
+  int rc = ffn_set_attr<0>();
+  if (rc == DADD_OK) rc = ffn_set_attr<1>();
+  if (rc == DADD_OK) rc = ffn_set_attr<2>();
+  if (rc == DADD_OK) rc = ffn_set_attr<3>();
+  return rc;
+}
+
+extern "C" int dadd_ffn_block_bytes(void) { return STREAM_BYTES; }
+
+extern "C" int dadd_ffn_block_f16(const void* x, const void* stream, const float* ln_g, const float* ln_b, float ln_eps,
+                                  const float* b1, const float* b2, const float* bp, const void* xres, void* out,
+                                  float* gn_ws, int gn_nchunk, int M, int HW, int Cin, void* s) {
+  DADD_REQUIRE(x && stream && ln_g && ln_b && b1 && b2 && bp && xres && out, "ffn_block: null pointer");
+  DADD_REQUIRE(Cin == C, "ffn_block: built for C = %d channels, got %d", C, Cin);
+  DADD_REQUIRE(M > 0 && HW > 0 && HW % RB == 0 && M % HW == 0, "ffn_block: M=%d must be whole samples of H*W=%d tokens, H*W a multiple of %d",
+               M, HW, RB);
+  DADD_REQUIRE((size_t)M * C * 2 < 0x7FF00000ull, "ffn_block: activation larger than the 2 GiB buffer window");
+  DADD_REQUIRE(gn_ws == nullptr || gn_nchunk == HW / 32, "ffn_block: GroupNorm partials come in chunks of 32 rows (gn_nchunk = H*W/32)");
+  DADD_REQUIRE(dadd_aligned16(x) && dadd_aligned16(stream) && dadd_aligned16(ln_g) && dadd_aligned16(ln_b) && dadd_aligned16(b1) &&
+                   dadd_aligned16(b2) && dadd_aligned16(bp) && dadd_aligned16(xres) && dadd_aligned16(out),
+               "ffn_block: pointers must be 16-byte aligned");
+  FfnArgs a;
+  a.x = static_cast<const half_t*>(x);
+  a.stream = static_cast<const half_t*>(stream);
+  a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps;
+  a.b1 = b1; a.b2 = b2; a.bp = bp;
+  a.xres = static_cast<const half_t*>(xres);
+  a.out = static_cast<half_t*>(out);
+  a.gn_ws = gn_ws;
+  a.M = M; a.HW = HW; a.gn_nchunk = gn_nchunk;
+  // diagnostics (scripts/ffn_bench.py): DADD_FFN_EXP selects a timing-only build
+  const char* e_exp = getenv("DADD_FFN_EXP");
+  const int exp = e_exp ? atoi(e_exp) : 0;
+  const double flop = 2.0 * (double)M * ((double)C * 2 * HID + (double)HID * C + (double)C * C);
+  const double bytes = 3.0 * (double)M * C * 2.0 + (double)STREAM_BYTES;
+  const dim3 grid(M / RB), block(512);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  switch (exp) {
+    case 1: dadd_launch({"ffn_block_kernel<1>", flop, bytes}, ffn_block_kernel<1>, grid, block, SMEM_BYTES, st, a); break;
+    case 2: dadd_launch({"ffn_block_kernel<2>", flop, bytes}, ffn_block_kernel<2>, grid, block, SMEM_BYTES, st, a); break;
+    case 3: dadd_launch({"ffn_block_kernel<3>", flop, bytes}, ffn_block_kernel<3>, grid, block, SMEM_BYTES, st, a); break;
+    default: dadd_launch({"ffn_block_kernel", flop, bytes}, ffn_block_kernel<0>, grid, block, SMEM_BYTES, st, a); break;
+  }
+  DADD_LAUNCH_CHECK();
+  return DADD_OK;
+}

@@ -87,6 +87,45 @@ def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tens
     return w16, w16.double().sum(dim=1).float(), bias.float()
 
 
+def lds_image(w: torch.Tensor) -> torch.Tensor:
+    """[R, 64] fp16 slab -> the LDS image the DMA kernels read fragments from: 128-byte rows, the eight 16-byte chunks
+    of row r stored at position ``chunk ^ ((r >> 1) & 7)`` (csrc/igemm_dma.hip ``lds_off``; an involution)."""
+    r = w.shape[0]
+    sw = (torch.arange(r) >> 1) & 7
+    idx = (torch.arange(8)[None, :] ^ sw[:, None])                       # image position p holds chunk p ^ sw
+    return w.reshape(r, 8, 8).gather(1, idx[:, :, None].expand(r, 8, 8)).reshape(r, 64).contiguous()
+
+
+def pack_ffn_stream(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, wp: torch.Tensor):
+    """Weights of a transformer block's tail in the order ``csrc/ffn_block.hip`` consumes them, as ready LDS images:
+    per 64 hidden channels five [128 x 64] pieces of ``ff.net.0.proj`` (rows: wave column wn -> [h0 g0 h1 g1], 16 rows
+    each, hidden index = chunk*64 + wn*32 + u*16 + e, gate row = 4C + hidden: diffusers ``GEGLU`` is
+    ``hidden, gate = proj(x).chunk(2)``), then two [160 x 64] pieces of ``ff.net.2`` (output channels x the chunk's
+    hidden channels); after the 20 chunks the ten [160 x 64] pieces of ``proj_out``.  Returns (stream fp16 1-D, bias of
+    the GEGLU rows in the same order)."""
+    c, hid = 320, 1280
+    assert tuple(w1.shape) == (2 * hid, c) and tuple(w2.shape) == (c, hid) and tuple(wp.shape)[:2] == (c, c)
+    w1, w2, wp = w1.to(F16), w2.to(F16), wp.reshape(c, c).to(F16)
+    pieces, bias = [], []
+    e = torch.arange(16)
+    for ch in range(hid // 64):
+        rows = []
+        for wn in range(2):
+            for u in range(2):
+                h = ch * 64 + wn * 32 + u * 16 + e
+                rows += [h, hid + h]
+                bias += [b1[h].float(), b1[hid + h].float()]
+        rows = torch.cat(rows)                                   # 128 rows of ff.net.0.proj
+        for kt in range(c // 64):
+            pieces.append(lds_image(w1[rows][:, kt * 64:(kt + 1) * 64]))
+        for nh in range(2):
+            pieces.append(lds_image(w2[nh * 160:(nh + 1) * 160, ch * 64:(ch + 1) * 64]))
+    for nh in range(2):
+        for kt in range(c // 64):
+            pieces.append(lds_image(wp[nh * 160:(nh + 1) * 160, kt * 64:(kt + 1) * 64]))
+    return torch.cat([p.reshape(-1) for p in pieces]).contiguous(), torch.cat(bias).contiguous()
+
+
 # GroupNorm (+ SiLU) applied inside the consuming 3x3 conv (DADD_PRE_GN, csrc/conv_halo.hip GNIN): the halo is normalised
 # in LDS by the loader waves; needs the producer's chunk partials, one source, <= 1024 input channels, the halo kernel
 GN_IN_CONV = True
@@ -113,6 +152,14 @@ LN_FOLD = "auto"
 LN_STATS_FROM_PRODUCER = True
 LN_STATS_MAX_PARTS = 8          # what the consumer stages in LDS (csrc/ln_lds.h); more parts (1280 channels from 64-column
                                 # tiles: 40) would be read from global memory in the epilogue — slower than the LayerNorm launch
+
+
+# The tail of a 320-channel transformer block (norm3 -> GEGLU -> FF-out -> proj_out) as ONE launch per 64-token row block
+# (csrc/ffn_block.hip): the (B*N) x 4C GEGLU output never leaves the CU.  Each workgroup streams the block's 2.6 MB of
+# weights, so it pays only while there are about as many row blocks as CUs (B = 4 at 64x64: 256); below FFN_MIN_BLOCKS
+# the three GEMM launches stay.
+FUSED_FFN = True
+FFN_MIN_BLOCKS = 128
 
 
 def fold_here(m: int, n: int, k: int, geglu: bool = False) -> bool:
@@ -532,6 +579,7 @@ class UNetPlan(_Plan):
         m_rows = b * h * w_
         fold1, fold2, fold3 = (fold_here(m_rows, 3 * c, c), fold_here(m_rows, c, c) and site not in self.a2,
                                fold_here(m_rows, 8 * c, c, True))
+        fused_tail = FUSED_FFN and c == 320 and (h * w_) % 64 == 0 and m_rows // 64 >= FFN_MIN_BLOCKS
         g = self.gn(x, None, self.f(site + ".norm.weight"), self.f(site + ".norm.bias"), 1e-6, 0)
         hs = self.conv(g, self.w(site + ".proj_in.weight"), shp, bias=self.f(site + ".proj_in.bias"),
                        taps=1, pad=0, ln_stats=LN_STATS_FROM_PRODUCER and LN_FOLD == "auto" and not fold1)
@@ -575,7 +623,7 @@ class UNetPlan(_Plan):
             else:
                 lnx = ln_of(h2, ".norm2")
             h3 = self.pool.get(shp)
-            if ext and not fold3 and c % 80 == 0:
+            if ext and not fold3 and c % 80 == 0 and not fused_tail:
                 st3 = self.be.zeros((c // 80, m_rows, 2), F32)
                 self.keep.append(st3)
                 kw2["ln_stats_out"] = st3
@@ -592,9 +640,33 @@ class UNetPlan(_Plan):
             self.pool.put(q)
             h3 = self.conv(att, self.w(tb + ".attn2.to_out.0.weight"), shp,
                            bias=self.f(tb + ".attn2.to_out.0.bias"), residual=h2, taps=1, pad=0,
-                           ln_stats=ext and not fold3)
+                           ln_stats=ext and not fold3 and not fused_tail)
             st3 = self.ln_partials.get(h3.data_ptr())
         self.pool.put(h2, att)
+        if fused_tail:               # norm3 -> GEGLU -> FF-out + h3 -> proj_out + x in one launch (csrc/ffn_block.hip)
+            def _tail():
+                u = self.prefix
+                st, b1p = pack_ffn_stream(self.sd[u + tb + ".ff.net.0.proj.weight"], self.sd[u + tb + ".ff.net.0.proj.bias"],
+                                          self.sd[u + tb + ".ff.net.2.weight"], self.sd[u + site + ".proj_out.weight"])
+                return self.dev(st), self.dev(b1p)
+            stream, b1p = self.cached((self.prefix + tb, "ffn_stream"), _tail)
+            if self.wcache is not None:
+                self.keep += [stream, b1p]
+            out = self.pool.get(shp)
+            nchunk = (h * w_) // 32
+            gkw = {}
+            if GN_FROM_EPILOGUE and nchunk <= 128 and (h * w_) * (c // 32) * 2 > GN_FUSED_MAX_BYTES:
+                ws = self.be.zeros((b * nchunk * GROUPS * 2,), F32)
+                self.keep.append(ws)
+                self.gn_partials[out.data_ptr()] = (ws, nchunk)
+                gkw = dict(gn_ws=ws, gn_nchunk=nchunk)
+            if ln_box[0] is not None:
+                self.pool.put(ln_box[0])
+            self.rec(self.be.ffn_block, h3.view(b, h * w_, c), stream, self.f(tb + ".norm3.weight"), self.f(tb + ".norm3.bias"),
+                     b1p, self.f(tb + ".ff.net.2.bias"), self.f(site + ".proj_out.bias"), x.view(b, h * w_, c),
+                     out.view(b, h * w_, c), **gkw)
+            self.pool.put(h3)
+            return out
         # GEGLU feed-forward
         if fold3 or st3 is not None:
             wf, c1, bf = self._ln_linear(tb, ".norm3", "geglu", [".ff.net.0.proj.weight"], ".ff.net.0.proj.bias", geglu=True)

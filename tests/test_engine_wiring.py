@@ -203,6 +203,38 @@ def test_unet_plan_groupnorm_inside_conv(unet_sd, monkeypatch):
     assert counts[False][0] - counts[True][0] == counts[True][1]      # one groupnorm op less per conv that normalises
 
 
+def test_unet_plan_fused_transformer_tail(unet_sd, monkeypatch):
+    """norm3 -> GEGLU -> FF-out -> proj_out as one op (csrc/ffn_block.hip) at the 320-channel sites: the plan replaces
+    three GEMM launches per block by ``ffn_block``, hands the GroupNorm partials of its output to the next resnet, and
+    matches the oracle; also the host-side packing of the weight stream against the kernel's addressing (unpack)."""
+    monkeypatch.setattr(E, "FFN_MIN_BLOCKS", 1)
+    monkeypatch.setattr(E, "GN_FUSED_MAX_BYTES", 0)
+    torch.manual_seed(2)
+    b, s = 1, 16                        # level 0: 256 tokens = 4 row blocks of 64
+    plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    names = [getattr(fn, "__name__", "") for fn, _, _ in plan.ops]
+    assert names.count("ffn_block") == 5
+    monkeypatch.setattr(E, "FUSED_FFN", False)
+    plain = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
+    assert len(plain.ops) - len(plan.ops) >= 10          # GEGLU + FF-out + proj_out -> one op, five times
+    x, cond = torch.randn(b, 4, s, s), torch.randn(b, 48, 768) * 0.5
+    t = torch.tensor([500])
+    with torch.no_grad():
+        ref = unet_forward(unet_sd, x, t, cond, delta_scale=3.0)
+        got = plan.forward(x, t, cond, lam=3.0)
+        got_plain = plain.forward(x, t, cond, lam=3.0)
+    tol = 6e-3 * max(1.0, ref.abs().max().item())
+    assert (ref - got).abs().max().item() < tol and (got - got_plain).abs().max().item() < tol
+    u = "unet.unet.down_blocks.0.attentions.0"
+    st, b1p = E.pack_ffn_stream(unet_sd[u + ".transformer_blocks.0.ff.net.0.proj.weight"], unet_sd[u + ".transformer_blocks.0.ff.net.0.proj.bias"],
+                                unet_sd[u + ".transformer_blocks.0.ff.net.2.weight"], unet_sd[u + ".proj_out.weight"])
+    w1, b1, w2, wp = TorchRefBackend.unpack_ffn_stream(st, b1p)
+    assert torch.equal(w1, unet_sd[u + ".transformer_blocks.0.ff.net.0.proj.weight"].half().float())
+    assert torch.equal(b1, unet_sd[u + ".transformer_blocks.0.ff.net.0.proj.bias"].float())
+    assert torch.equal(w2, unet_sd[u + ".transformer_blocks.0.ff.net.2.weight"].half().float())
+    assert torch.equal(wp, unet_sd[u + ".proj_out.weight"].reshape(320, 320).half().float())
+
+
 def test_unet_plan_baseline_mode(full_sd):
     torch.manual_seed(2)
     sd = full_sd

@@ -567,6 +567,44 @@ def test_attn2_fused(hip, b, hw, c):
                         hip.zeros((b, 64, c), F16))          # fewer than 128 tokens per sample
 
 
+@pytest.mark.parametrize("b,hw", [(1, 64), (2, 256), (4, 4096)])
+def test_ffn_block(hip, b, hw):
+    """Transformer-block tail in one launch (csrc/ffn_block.hip): LayerNorm 3 -> GEGLU projection -> FF-out + residual ->
+    proj_out + outer residual, against the same chain in torch with the unfused launches' rounding points (normalised
+    rows, GEGLU output, h4, result in fp16; fp32 everywhere else) — through the packed weight stream the device reads.
+    Tolerance: the result passes two K = 320 / 1280 fp16-operand GEMMs behind rounded intermediates: 6e-3 + 4e-3 |ref|.
+    GroupNorm partials: sums of the STORED values (1e-5 relative); launches are bit-reproducible (the ring protocol)."""
+    from progressive_stable_diffusion_amd.engine import pack_ffn_stream
+    c, hid = 320, 1280
+    x = (rnd((b, hw, c), 700, 1.0).float() + 0.5 * torch.randn(b, hw, 1, generator=torch.Generator().manual_seed(701))).to(F16)
+    xres = rnd((b, hw, c), 702)
+    w1, w2 = rnd((2 * hid, c), 703, 1.0 / math.sqrt(c)), rnd((c, hid), 704, 1.0 / math.sqrt(hid))
+    wp = rnd((c, c, 1, 1), 705, 1.0 / math.sqrt(c))
+    b1, b2, bp = rnd((2 * hid,), 706, 0.2, F32), rnd((c,), 707, 0.2, F32), rnd((c,), 708, 0.2, F32)
+    g = torch.Generator().manual_seed(709)
+    gam, bet = 1.0 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    stream, b1p = pack_ffn_stream(w1, b1, w2, wp)
+    nchunk = hw // 32
+    o_ref, ws_ref = torch.zeros(b, hw, c, dtype=F16), torch.zeros(b * nchunk * 64)
+    REF.ffn_block(x, stream, gam, bet, b1p, b2, bp, xres, o_ref, gn_ws=ws_ref, gn_nchunk=nchunk)
+    args = [dev(hip, t) for t in (x, stream, gam, bet, b1p, b2, bp, xres)]
+    o, ws = hip.zeros((b, hw, c), F16), hip.zeros((b * nchunk * 64,), F32)
+    hip.ffn_block(*args, o, gn_ws=ws, gn_nchunk=nchunk)
+    hip.synchronize()
+    close(o, o_ref, 6e-3, 4e-3, f"ffn_block {b}x{hw}")
+    oc = o.float().cpu().reshape(b, nchunk, 32, 32, c // 32)
+    want = torch.stack([oc.sum(dim=(2, 4)), (oc * oc).sum(dim=(2, 4))], dim=-1).reshape(-1)
+    assert (ws.cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-4
+    o2 = hip.zeros((b, hw, c), F16)
+    for _ in range(3):
+        hip.ffn_block(*args, o2)                   # no partials requested
+    hip.synchronize()
+    assert torch.equal(o2, o)
+    with pytest.raises(ValueError):
+        hip.ffn_block(dev(hip, x[:, :32].contiguous()), *args[1:7], dev(hip, xres[:, :32].contiguous()),
+                      hip.zeros((b, 32, c), F16))      # fewer than 64 tokens per sample
+
+
 def test_tri_xattn_lambda_zero_equals_two_pathways(hip):
     """routing_gates.py:160,177-178: delta_scale == 0 must skip the delta pathway exactly; garbage
     (even NaN) in the delta tokens must not leak."""

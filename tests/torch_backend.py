@@ -235,6 +235,60 @@ class TorchRefBackend:
             o = out.float().reshape(b * hw, ln_stats_out.shape[0], -1)
             ln_stats_out.copy_(torch.stack([o.sum(dim=-1), (o * o).sum(dim=-1)], dim=-1).permute(1, 0, 2))
 
+    @staticmethod
+    def unpack_ffn_stream(stream, b1):
+        """Inverse of ``engine.pack_ffn_stream``: (w1 [2560,320], b1 [2560], w2 [320,1280], wp [320,320]) from the piece
+        stream — decoded piece by piece with the kernel's own addressing (image position p of row r holds chunk
+        p ^ ((r >> 1) & 7)), so the CPU suite checks the packing the device consumes."""
+        c, hid = 320, 1280
+
+        def unimage(t, rows):
+            t = t.reshape(rows, 8, 8)
+            sw = (torch.arange(rows) >> 1) & 7
+            idx = torch.arange(8)[None, :] ^ sw[:, None]                 # chunk q sits at position q ^ sw
+            return t.gather(1, idx[:, :, None].expand(rows, 8, 8)).reshape(rows, 64)
+        w1, w2, wp = torch.zeros(2 * hid, c), torch.zeros(c, hid), torch.zeros(c, c)
+        bias = torch.zeros(2 * hid)
+        st, off, boff = stream.float().cpu(), 0, 0
+        e = torch.arange(16)
+        for ch in range(hid // 64):
+            rows = []
+            for wn in range(2):
+                for u in range(2):
+                    h = ch * 64 + wn * 32 + u * 16 + e
+                    rows += [h, hid + h]
+            rows = torch.cat(rows)
+            bias[rows] = b1.float().cpu()[boff:boff + 128]
+            boff += 128
+            for kt in range(c // 64):
+                w1[rows, kt * 64:(kt + 1) * 64] = unimage(st[off:off + 128 * 64], 128)
+                off += 128 * 64
+            for nh in range(2):
+                w2[nh * 160:(nh + 1) * 160, ch * 64:(ch + 1) * 64] = unimage(st[off:off + 160 * 64], 160)
+                off += 160 * 64
+        for nh in range(2):
+            for kt in range(c // 64):
+                wp[nh * 160:(nh + 1) * 160, kt * 64:(kt + 1) * 64] = unimage(st[off:off + 160 * 64], 160)
+                off += 160 * 64
+        assert off == st.numel()
+        return w1, bias, w2, wp
+
+    def ffn_block(self, x, stream, ln_g, ln_b, b1, b2, bp, xres, out, gn_ws=None, gn_nchunk=0, ln_eps=1e-5):
+        """csrc/ffn_block.hip in torch: the four rounding points of the unfused launches (normalised rows, GEGLU output,
+        h4, result), everything else fp32."""
+        import torch.nn.functional as Fn
+        b, hw, c = x.shape
+        w1, b1u, w2, wp = self.unpack_ffn_stream(stream, b1)
+        xn = Fn.layer_norm(x.float(), (c,), ln_g.float(), ln_b.float(), ln_eps).to(torch.float16).float()
+        h = xn @ w1.T + b1u
+        gg = (h[..., :1280] * Fn.gelu(h[..., 1280:])).to(torch.float16).float()
+        h4 = (gg @ w2.T + b2.float() + x.float()).to(torch.float16).float()
+        out.copy_((h4 @ wp.T + bp.float() + xres.float()).to(out.dtype))
+        if gn_ws is not None:
+            o = out.float().reshape(b, gn_nchunk, hw // gn_nchunk, 32, c // 32)
+            st = torch.stack([o.sum(dim=(2, 4)), (o * o).sum(dim=(2, 4))], dim=-1)      # [b][chunk][32][2]
+            gn_ws[:b * gn_nchunk * 64].copy_(st.reshape(-1))
+
     def tri_xattn(self, q, kv, out, gates, lam, mode, heads, lam_dev=None):
         if lam_dev is not None:
             lam = float(lam_dev.reshape(-1)[0])
