@@ -242,6 +242,20 @@ int dadd_ffn_block_f16(const void* x, const void* stream, const float* ln_g, con
                        int gn_nchunk, int M, int HW, int C, void* stream_handle);
 int dadd_ffn_block_bytes(void);
 
+/* The head of one transformer block at a 320-channel site as ONE launch per 64-token row block (csrc/tf_head.hip):
+ *   hs = proj_in( GroupNorm(x) ) + bp;   qkv = LayerNorm1(hs) [Wq | Wk | Wv]^T
+ * Replaces norm / proj_in / norm1 / attn1.to_q,k,v of diffusers' Transformer2DModel + BasicTransformerBlock (the UNet
+ * body behind /root/reference/src/models/unet/unet.py:140-144).  x, hs: [M][320] fp16, qkv: [M][960]
+ * (q | k | v blocks of 320 columns); gn_ws: GroupNorm chunk partials of x written by its producer,
+ * [M/HW][gn_nchunk][32][2] fp32; stream: dadd_tf_head_bytes() bytes of pre-swizzled weight pieces
+ * (engine.pack_head_stream). */
+int dadd_tf_head_f16(const void* x, const void* stream, const float* gn_ws, int gn_nchunk, const float* gn_g,
+                     const float* gn_b, float gn_eps, const float* bp, const float* ln_g, const float* ln_b, float ln_eps,
+                     void* hs, void* qkv, int M, int HW, int C, void* stream_handle);
+int dadd_tf_head_bytes(void);
+/* diagnostics: per-workgroup cycle stamps (16 x uint64 each) of the following dadd_tf_head_f16 launches; NULL = off */
+int dadd_tf_head_debug(void* buf);
+
 /* ---- sampler glue --------------------------------------------------------------------------
  * Sinusoidal timestep features (flip_sin_to_cos, shift 0): out[m][0:dim/2]=cos, [dim/2:]=sin. */
 int dadd_timestep_features_f32(const int64_t* t, float* out, int M, int dim, void* stream);

@@ -273,6 +273,18 @@ class HipBackend:
         L.check(self.lib.dadd_ffn_block_f16(_p(x), _p(stream), _p(ln_g), _p(ln_b), float(ln_eps), _p(b1), _p(b2), _p(bp),
                                             _p(xres), _p(out), _p(gn_ws), int(gn_nchunk), b * hw, hw, c, self.s))
 
+    def tf_head(self, x, stream, gn_ws, gn_nchunk, gn_g, gn_b, bp, ln_g, ln_b, hs, qkv, gn_eps=1e-6, ln_eps=1e-5):
+        """Transformer-block head in one launch (csrc/tf_head.hip): x, hs [B,HW,320], qkv [B,HW,960] fp16; ``gn_ws`` the
+        producer's GroupNorm chunk partials of x ([B*gn_nchunk*64] fp32); ``stream`` from ``engine.pack_head_stream``."""
+        b, hw, c = x.shape
+        assert hs.shape == x.shape and qkv.shape == (b, hw, 3 * c) and x.dtype == hs.dtype == qkv.dtype == torch.float16
+        assert stream.dtype == torch.float16 and stream.numel() * 2 == self.lib.dadd_tf_head_bytes()
+        assert gn_ws.dtype == torch.float32 and gn_ws.numel() >= b * gn_nchunk * 64
+        assert all(t.dtype == torch.float32 and t.numel() == c for t in (gn_g, gn_b, bp, ln_g, ln_b))
+        assert x.is_contiguous() and hs.is_contiguous() and qkv.is_contiguous()
+        L.check(self.lib.dadd_tf_head_f16(_p(x), _p(stream), _p(gn_ws), int(gn_nchunk), _p(gn_g), _p(gn_b), float(gn_eps),
+                                          _p(bp), _p(ln_g), _p(ln_b), float(ln_eps), _p(hs), _p(qkv), b * hw, hw, c, self.s))
+
     def timestep_features(self, t, out):
         assert t.dtype == torch.int64 and out.dtype == torch.float32
         L.check(self.lib.dadd_timestep_features_f32(_p(t), _p(out), out.shape[0], out.shape[1], self.s))

@@ -12,6 +12,7 @@ int dadd_init_attention();
 int dadd_init_norm();
 int dadd_init_attn2_fused();
 int dadd_init_ffn_block();
+int dadd_init_tf_head();
 
 namespace {
 thread_local char g_err[512] = "";
@@ -60,7 +61,8 @@ int dadd_init(void) {
   if (rc == DADD_OK) rc = dadd_init_attention();
   if (rc == DADD_OK) rc = dadd_init_norm();
   if (rc == DADD_OK) rc = dadd_init_attn2_fused();
-  return rc != DADD_OK ? rc : dadd_init_ffn_block();
+  if (rc == DADD_OK) rc = dadd_init_ffn_block();
+  return rc != DADD_OK ? rc : dadd_init_tf_head();
 }
 
 int dadd_device_info(int device, int64_t out[4]) {

@@ -173,7 +173,25 @@ __global__ __launch_bounds__(512, 2) void ffn_block_kernel(const FfnArgs p) {
   // ---- MFMA waves: (wr, wn) = (row half of the 64 tokens, column half of every piece)
   const int wr = wave >> 1, wn = wave & 1;
   const int mc = lane & 15, fq = lane >> 4, g = fq;
+  // The weight stream comes from HBM (every site has its own 2.6 MB, last touched one denoising step ago), and a ring of
+  // 100 KB in flight against that latency gives a CU ~50 GB/s, while the same ring fed from L2 runs at 120 GB/s
+  // (scripts/micro/stream_lds.hip, profiles/r03_k_stream_lds.txt).  So while they wait for the token tile the MFMA waves
+  // PREFETCH the stream into this XCD's L2: the (up to) 32 workgroups of an XCD — blocks b, b + 8, ... under the
+  // observed round-robin dispatch; a different placement only costs speed — touch one dword of every 128-byte line of
+  // 1/32 of it each.  The sum is consumed by a store that never executes.
+  unsigned pf = 0;
+  {
+    const int nshare = max(1, (int)gridDim.x >> 3), share = (blockIdx.x >> 3) % nshare;
+    constexpr int NLINES = STREAM_BYTES / 128;
+    const int per = (NLINES + nshare - 1) / nshare;
+    const char* sp = reinterpret_cast<const char*>(p.stream);
+    for (int i = wave * 64 + lane; i < per; i += 256) {
+      const int line = share * per + i;
+      if (line < NLINES) pf += *reinterpret_cast<const unsigned*>(sp + (size_t)line * 128);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pf == 0x9e3779b9u && p.M < 0) p.out[0] = (half_t)0.f;
   __builtin_amdgcn_s_barrier();             // B0
 
   // LayerNorm 3 in LDS: four lanes per row, ten 16-byte chunks each; exact two-pass variance; fp16 result in place

@@ -175,7 +175,9 @@ def _ddim_sample_ip(module: DiffusionModuleWithIP, target_labels: Tensor, source
         latents = latents.to(device=device, dtype=torch.float32)
     side = latents.shape[-1]
 
-    timesteps = torch.linspace(T - 1, 0, steps=sampling_steps, dtype=torch.long, device=device)
+    # (:389-395) the reference builds this grid on the device; the integers are the same on the CPU (asserted on the GPU
+    # in tests/test_gpu_parity.py), where the engine's host-side step tables need them without a device read
+    timesteps = torch.linspace(T - 1, 0, steps=sampling_steps, dtype=torch.long)
     embed_cond = _prepare_conditioning(module, target_labels, source_labels, structure_image,
                                        image_scale=image_scale, leace=leace)
     embed_uncond = None

@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdadd_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "attn2_fused.hip", "ffn_block.hip", "norm.hip", "attention.hip", "elementwise.hip",
+SOURCES = ("igemm.hip", "igemm_dma.hip", "conv_halo.hip", "attn2_fused.hip", "ffn_block.hip", "tf_head.hip", "norm.hip", "attention.hip", "elementwise.hip",
            "conditioning.hip", "api.hip")
 
 DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
@@ -63,6 +63,9 @@ PROTOTYPES = {
     "dadd_attn2_fused_f16": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, f32, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_ffn_block_f16": (C.c_int, [vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "dadd_ffn_block_bytes": (C.c_int, []),
+    "dadd_tf_head_f16": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, f32, vp, vp, vp, f32, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_tf_head_bytes": (C.c_int, []),
+    "dadd_tf_head_debug": (C.c_int, [vp]),
     "dadd_tri_xattn_f16": (C.c_int, [vp, vp, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp]),
     "dadd_timestep_features_f32": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

@@ -213,10 +213,11 @@ def test_unet_plan_fused_transformer_tail(unet_sd, monkeypatch):
     b, s = 1, 16                        # level 0: 256 tokens = 4 row blocks of 64
     plan = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
     names = [getattr(fn, "__name__", "") for fn, _, _ in plan.ops]
-    assert names.count("ffn_block") == 5
+    assert names.count("ffn_block") == 5 and names.count("tf_head") == 5       # head and tail of the five 320-channel blocks
     monkeypatch.setattr(E, "FUSED_FFN", False)
+    monkeypatch.setattr(E, "FUSED_HEAD", False)
     plain = E.UNetPlan(TorchRefBackend(), unet_sd, b, s)
-    assert len(plain.ops) - len(plan.ops) >= 10          # GEGLU + FF-out + proj_out -> one op, five times
+    assert len(plain.ops) - len(plan.ops) >= 20          # GEGLU + FF-out + proj_out -> one op and norm + proj_in + qkv -> one op, five times
     x, cond = torch.randn(b, 4, s, s), torch.randn(b, 48, 768) * 0.5
     t = torch.tensor([500])
     with torch.no_grad():
@@ -233,6 +234,10 @@ def test_unet_plan_fused_transformer_tail(unet_sd, monkeypatch):
     assert torch.equal(b1, unet_sd[u + ".transformer_blocks.0.ff.net.0.proj.bias"].float())
     assert torch.equal(w2, unet_sd[u + ".transformer_blocks.0.ff.net.2.weight"].half().float())
     assert torch.equal(wp, unet_sd[u + ".proj_out.weight"].reshape(320, 320).half().float())
+    hst = E.pack_head_stream(unet_sd[u + ".proj_in.weight"], *[unet_sd[u + f".transformer_blocks.0.attn1.to_{n}.weight"] for n in "qkv"])
+    wpi, wqkv = TorchRefBackend.unpack_head_stream(hst)
+    assert torch.equal(wpi, unet_sd[u + ".proj_in.weight"].reshape(320, 320).half().float())
+    assert torch.equal(wqkv, torch.cat([unet_sd[u + f".transformer_blocks.0.attn1.to_{n}.weight"] for n in "qkv"]).half().float())
 
 
 def test_unet_plan_baseline_mode(full_sd):

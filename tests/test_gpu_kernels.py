@@ -605,6 +605,39 @@ def test_ffn_block(hip, b, hw):
                       hip.zeros((b, 32, c), F16))      # fewer than 64 tokens per sample
 
 
+@pytest.mark.parametrize("b,hw,nchunk", [(1, 64, 1), (2, 256, 4), (4, 4096, 64), (4, 4096, 128)])
+def test_tf_head(hip, b, hw, nchunk):
+    """Transformer-block head in one launch (csrc/tf_head.hip): GroupNorm from chunk partials -> proj_in -> LayerNorm 1 ->
+    q|k|v, against the same chain in torch with the unfused launches' rounding points.  hs passes one K = 320 GEMM behind
+    a rounded input (3e-3 + 3e-3 |ref|); q|k|v a second one behind LayerNorm of the rounded hs (6e-3 + 4e-3 |ref|)."""
+    from progressive_stable_diffusion_amd.engine import pack_head_stream
+    c = 320
+    x = (rnd((b, hw, c), 720).float() * (1.0 + 0.5 * torch.randn(1, 1, c, generator=torch.Generator().manual_seed(721)))
+         + torch.randn(b, 1, c, generator=torch.Generator().manual_seed(722))).to(F16)
+    wp = rnd((c, c, 1, 1), 723, 1.0 / math.sqrt(c))
+    wq, wk, wv = (rnd((c, c), 724 + i, 1.0 / math.sqrt(c)) for i in range(3))
+    bp = rnd((c,), 727, 0.2, F32)
+    g = torch.Generator().manual_seed(728)
+    gg, gb = 1.0 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    lg, lb = 1.0 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    xs = x.float().reshape(b, nchunk, hw // nchunk, 32, c // 32)
+    ws = torch.stack([xs.sum(dim=(2, 4)), (xs * xs).sum(dim=(2, 4))], dim=-1).reshape(-1).contiguous()     # [b][chunk][32][2]
+    stream = pack_head_stream(wp, wq, wk, wv)
+    hs_ref, qkv_ref = torch.zeros(b, hw, c, dtype=F16), torch.zeros(b, hw, 3 * c, dtype=F16)
+    REF.tf_head(x, stream, ws, nchunk, gg, gb, bp, lg, lb, hs_ref, qkv_ref)
+    args = [dev(hip, t) for t in (x, stream, ws)] + [nchunk] + [dev(hip, t) for t in (gg, gb, bp, lg, lb)]
+    hs, qkv = hip.zeros((b, hw, c), F16), hip.zeros((b, hw, 3 * c), F16)
+    hip.tf_head(*args, hs, qkv)
+    hip.synchronize()
+    close(hs, hs_ref, 3e-3, 3e-3, f"tf_head hs {b}x{hw}")
+    close(qkv, qkv_ref, 6e-3, 4e-3, f"tf_head qkv {b}x{hw}")
+    hs2, qkv2 = hip.zeros((b, hw, c), F16), hip.zeros((b, hw, 3 * c), F16)
+    for _ in range(3):
+        hip.tf_head(*args, hs2, qkv2)
+    hip.synchronize()
+    assert torch.equal(hs2, hs) and torch.equal(qkv2, qkv)
+
+
 def test_tri_xattn_lambda_zero_equals_two_pathways(hip):
     """routing_gates.py:160,177-178: delta_scale == 0 must skip the delta pathway exactly; garbage
     (even NaN) in the delta tokens must not leak."""

@@ -522,22 +522,32 @@ def test_vae_decode_512_matches_oracle(hip, full_sd):
     assert d.max().item() < 3e-2 and d.mean().item() < 2e-3
 
 
-def test_unet_call_512_matches_oracle(hip, full_sd):
+@pytest.mark.parametrize("bench_plan", [False, True])
+def test_unet_call_512_matches_oracle(hip, full_sd, bench_plan, monkeypatch):
     """One eps call at BASELINE size (64x64 latent, B = 1, lambda = 3): the 64x64-level kernels (halo conv W = 64,
-    flash d = 40 at 4096 keys, the fused attn2 when eligible) against the oracle."""
-    from progressive_stable_diffusion_amd.engine import UNetPlan
-    plan = UNetPlan(hip, full_sd, 1, 64)
+    flash d = 40 at 4096 keys) against the oracle.  ``bench_plan``: with the fusions the B = 4 bench plan uses at the
+    64x64 sites forced on at B = 1 too — attn2 in one kernel, the transformer blocks' head (GroupNorm + proj_in + norm1 +
+    q|k|v, csrc/tf_head.hip) and tail (norm3 + GEGLU + FF-out + proj_out, csrc/ffn_block.hip) in one launch each."""
+    from progressive_stable_diffusion_amd import engine as E
+    if bench_plan:
+        monkeypatch.setattr(E, "FFN_MIN_BLOCKS", 1)
+        monkeypatch.setattr(E, "A2_MIN_TILES", 1)
+    plan = E.UNetPlan(hip, full_sd, 1, 64)
+    names = [getattr(fn, "__name__", "") for fn, _, _ in plan.ops]
+    assert (names.count("ffn_block"), names.count("tf_head")) == ((5, 5) if bench_plan else (0, 0))
     g = torch.Generator().manual_seed(17)
     x = torch.randn(1, 4, 64, 64, generator=g)
     cond = torch.randn(1, 48, 768, generator=g) * 0.5
     t = torch.tensor([650])
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    with torch.no_grad():
-        ref = unet_forward(full_sd, x, t, cond, delta_scale=3.0)
+    if "u512" not in _ORACLE_RUNS:
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        with torch.no_grad():
+            _ORACLE_RUNS["u512"] = unet_forward(full_sd, x, t, cond, delta_scale=3.0)
+    ref = _ORACLE_RUNS["u512"]
     got = plan.forward(x.to(DEV), t.to(DEV), cond.to(DEV), lam=3.0)
     hip.synchronize()
     err = (got.cpu() - ref).abs().max().item()
-    print(f"unet 512 call: max err {err:.3e} (max |eps| {ref.abs().max():.3f})")
+    print(f"unet 512 call (bench plan fusions {bench_plan}): max err {err:.3e} (max |eps| {ref.abs().max():.3f})")
     assert err < 1e-2 * max(1.0, ref.abs().max().item()), err
 
 

@@ -289,6 +289,42 @@ class TorchRefBackend:
             st = torch.stack([o.sum(dim=(2, 4)), (o * o).sum(dim=(2, 4))], dim=-1)      # [b][chunk][32][2]
             gn_ws[:b * gn_nchunk * 64].copy_(st.reshape(-1))
 
+    @staticmethod
+    def unpack_head_stream(stream):
+        """Inverse of ``engine.pack_head_stream``: (proj_in [320,320], to_q|to_k|to_v [960,320])."""
+        c = 320
+        st, off = stream.float().cpu(), 0
+        sw = (torch.arange(160) >> 1) & 7
+        idx = (torch.arange(8)[None, :] ^ sw[:, None])[:, :, None].expand(160, 8, 8)
+        out = []
+        for rows in (c, 3 * c):
+            w = torch.zeros(rows, c)
+            for nh in range(rows // 160):
+                for kt in range(c // 64):
+                    w[nh * 160:(nh + 1) * 160, kt * 64:(kt + 1) * 64] = st[off:off + 160 * 64].reshape(160, 8, 8).gather(1, idx).reshape(160, 64)
+                    off += 160 * 64
+            out.append(w)
+        assert off == st.numel()
+        return out
+
+    def tf_head(self, x, stream, gn_ws, gn_nchunk, gn_g, gn_b, bp, ln_g, ln_b, hs, qkv, gn_eps=1e-6, ln_eps=1e-5):
+        """csrc/tf_head.hip in torch: GroupNorm from the producer's chunk partials (x * scale + shift, fp16), proj_in + bias
+        (fp16 hs), LayerNorm 1 (fp16), q|k|v (fp16)."""
+        import torch.nn.functional as Fn
+        b, hw, c = x.shape
+        wp, wqkv = self.unpack_head_stream(stream)
+        st = gn_ws[:b * gn_nchunk * 64].double().reshape(b, gn_nchunk, 32, 2).sum(dim=1)
+        n = hw * (c // 32)
+        mu = st[..., 0] / n
+        rstd = 1.0 / torch.sqrt((st[..., 1] / n - mu * mu).clamp_min(0.0) + gn_eps)
+        sc = rstd.float().repeat_interleave(c // 32, dim=1) * gn_g.float()                 # [b][c]
+        sh = gn_b.float() - mu.float().repeat_interleave(c // 32, dim=1) * sc
+        g = (x.float() * sc[:, None, :] + sh[:, None, :]).to(torch.float16).float()
+        h = (g @ wp.T + bp.float()).to(torch.float16)
+        hs.copy_(h)
+        ln = Fn.layer_norm(h.float(), (c,), ln_g.float(), ln_b.float(), ln_eps).to(torch.float16).float()
+        qkv.copy_((ln @ wqkv.T).to(qkv.dtype))
+
     def tri_xattn(self, q, kv, out, gates, lam, mode, heads, lam_dev=None):
         if lam_dev is not None:
             lam = float(lam_dev.reshape(-1)[0])
