@@ -96,7 +96,12 @@ __device__ __forceinline__ int kpanel_off(int row, int chunk) {
 // probabilities are converted pairwise, and — when the head dim leaves a spare column in its
 // 16-multiple (d = 40 -> 48) — a column of ones in V makes the PV MFMA produce the softmax row sums.
 // (two blocks per CU for the small head dims: 256 VGPRs per lane at most — at 260 the d = 40 kernel ran one block per
-// CU and took 242 instead of 172 us)
+// CU and took 242 instead of 172 us.  Round 3 built the one-block-per-CU variant VERDICT r2 asked for — S(t+1) and
+// PV(t-1) MFMAs in one basic block with the softmax of tile t, two score and two probability register sets, four K/V
+// buffers: it needs ~304 live registers per lane, beyond the 256 ARCHITECTURAL VGPRs a wave has even when it owns all
+// 512 (the other 256 are AGPRs, reachable by VALU only through v_accvgpr moves): hipcc emitted 1,160 of those moves per
+// iteration pair and the kernel took 327 us against 171 (same box, profiles/r03_o_flash_pipe_ab.txt).  Not kept; what
+// the counters say about this kernel is in profiles/r03_n_pmc_flash.txt: VALU issuing 50 % of the time, MFMA pipe 30 %.)
 template <int DR, int QF, bool PREFETCH>
 __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const FlashArgs p) {
   constexpr bool DEEP = PREFETCH && DR <= 40;   // two tiles in flight where the registers allow it
@@ -265,8 +270,13 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
         mx = vmax3(mx, sacc[kf][f][0], sacc[kf][f][1]);
         mx = vmax3(mx, sacc[kf][f][2], sacc[kf][f][3]);
       }
-      mx = vmax2(mx, __shfl_xor(mx, 16, 64));
-      mx = vmax2(mx, __shfl_xor(mx, 32, 64));
+      {   // the maximum over the four lanes that share a query column: permlane swaps (VALU), not ds_bpermute + wait
+        float ua, ub;
+        dadd_pair16(mx, ua, ub);
+        mx = vmax2(ua, ub);
+        dadd_pair32(mx, ua, ub);
+        mx = vmax2(ua, ub);
+      }
       const float mnew = vmax2(mrow[f], mx * p.scale_log2);      // running max in log2 units
       const bool moved = mnew > mrow[f];
       float rs = 0.f;
@@ -285,8 +295,7 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
         for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
       }
       if (!SUMCOL) {
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = dadd_sum_x16x32(rs);
         lrow[f] += rs;
       }
       mrow[f] = mnew;
@@ -478,8 +487,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
         sacc[f][r] *= p.scale_log2;
         m = fmaxf(m, sacc[f][r]);
       }
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      mx[f] = fmaxf(m, __shfl_xor(m, 32, 64));
+      mx[f] = dadd_max_x16x32(m);
     }
     if (JOINT) {
       float m = mx[0];
@@ -496,8 +504,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
         sacc[f][r] = exp2f(sacc[f][r] - mx[f]);
         s += sacc[f][r];
       }
-      s += __shfl_xor(s, 16, 64);
-      sm[f] = s + __shfl_xor(s, 32, 64);
+      sm[f] = dadd_sum_x16x32(s);
     }
     if (JOINT) {
       float s = 0.f;

@@ -207,13 +207,11 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
       f4 v = acc[j][i];
       if (fold) v = lrs[i] * (v - lmu[i] * fc1[j]) + fd[j];
       float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = dadd_max_x16x32(mx);
       const float e0 = __builtin_amdgcn_exp2f(v[0] - mx), e1 = __builtin_amdgcn_exp2f(v[1] - mx);
       const float e2 = __builtin_amdgcn_exp2f(v[2] - mx), e3 = __builtin_amdgcn_exp2f(v[3] - mx);
       float sum = (e0 + e1) + (e2 + e3);
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = dadd_sum_x16x32(sum);
       const float inv = __builtin_amdgcn_rcpf(sum);
       const h4 o = {(half_t)(e0 * inv), (half_t)(e1 * inv), (half_t)(e2 * inv), (half_t)(e3 * inv)};
       const int k = wn * 192 + j * 16 + g * 4;         // column of P = K index of phase 2
@@ -276,10 +274,8 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
           }
         }
         if (p.ln_stats) {     // the next LayerNorm's row partials (sum, sum of squares over this wave's 80 columns)
-          rs1 += __shfl_xor(rs1, 16, 64);
-          rs2 += __shfl_xor(rs2, 16, 64);
-          rs1 += __shfl_xor(rs1, 32, 64);
-          rs2 += __shfl_xor(rs2, 32, 64);
+          rs1 = dadd_sum_x16x32(rs1);
+          rs2 = dadd_sum_x16x32(rs2);
           if (g == 0)
             reinterpret_cast<dadd_f2*>(p.ln_stats)[(size_t)(nt * 2 + wn) * ((size_t)p.B * p.HW) + m] = dadd_f2{rs1, rs2};
         }

@@ -98,6 +98,41 @@ __device__ __forceinline__ dadd_f2 dadd_gelu2(dadd_f2 x) {
   const dadd_f2 erf_abs = __builtin_elementwise_fma(-p * t, e, one);
   return 0.5f * x * (one + __builtin_elementwise_copysign(erf_abs, x));
 }
+// Exchange with the lane 16 (32) away WITHOUT the LDS crossbar: __shfl_xor(v, 16 / 32, 64) compiles to ds_bpermute_b32
+// plus an s_waitcnt lgkmcnt(0) — ~120 cycles of exposed latency per call in the softmax reductions, eight per 64-key
+// tile in flash_kernel — while gfx950's v_permlane16_swap / v_permlane32_swap are plain VALU instructions.
+// swap(x, x) leaves {r0, r0, r2, r2} / {r1, r1, r3, r3} (16-lane rows; resp. the two 32-lane halves) in its two results:
+// both partners of every pair hold both values.
+__device__ __forceinline__ void dadd_pair16(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];   // (a bit_cast of the vector element itself reads element 0 for both)
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void dadd_pair32(float v, float& a, float& b) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];   // (a bit_cast of the vector element itself reads element 0 for both)
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+// sum / max over the four lanes {l, l^16, l^32, l^48} (every lane gets the result; the order of the additions is the
+// same in all four lanes: (r0 + r1) + (r2 + r3))
+__device__ __forceinline__ float dadd_sum_x16x32(float v) {
+  float a, b;
+  dadd_pair16(v, a, b);
+  v = a + b;
+  dadd_pair32(v, a, b);
+  return a + b;
+}
+__device__ __forceinline__ float dadd_max_x16x32(float v) {
+  float a, b;
+  dadd_pair16(v, a, b);
+  v = fmaxf(a, b);
+  dadd_pair32(v, a, b);
+  return fmaxf(a, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -239,15 +239,19 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmArgs p, i
 }
 
 // Finish of a split-K launch whose output feeds a GroupNorm (DADD_EPI_GNSTAT): same sums and epilogue as above, but a
-// block owns 64 rows x CB columns (whole groups) and also writes their (sum, sum of squares) per group into the
-// GroupNorm's chunk partials [B][Ho*Wo/64][32][2] — the consumer then needs no statistics pass.  Fixed summation order.
-template <int CB>
+// block owns R rows x CB columns (whole groups) and also writes their (sum, sum of squares) per group into the
+// GroupNorm's chunk partials [B][Ho*Wo/R][32][2] — the consumer then needs no statistics pass.  Fixed summation order.
+// R = 16 (the engine's choice): 4x the blocks of the 64-row version on the 16x16 / 8x8 maps, where that one ran 32-128
+// blocks of serial, dependent slab loads (16-21 us per launch for 23-31 MB); here every thread has its (up to three) rows
+// times four slabs in flight.
+template <int CB, int R>
 __global__ __launch_bounds__(256) void splitk_finish_gn_kernel(const IgemmArgs p, int nsplit) {
   constexpr int Q = CB / 4, RL = 256 / Q;          // channel quads per row, row lanes (40 x 6 or 32 x 8)
+  constexpr int NR = (R + RL - 1) / RL;            // rows per thread
   __shared__ float red[RL][CB][2];
   const int t = threadIdx.x, q = t % Q, rl = t / Q;
   const int n = blockIdx.y * CB + q * 4;
-  const int m_base = blockIdx.x * 64;
+  const int m_base = blockIdx.x * R;
   const int HoWo = p.Ho * p.Wo;
   const int bsmp = m_base / HoWo;
   const size_t sstride = (size_t)p.M * p.N;
@@ -256,20 +260,44 @@ __global__ __launch_bounds__(256) void splitk_finish_gn_kernel(const IgemmArgs p
     f4 add = {0.f, 0.f, 0.f, 0.f};
     if (p.flags & DADD_EPI_BIAS) add = *reinterpret_cast<const f4*>(p.bias + n);
     if (p.flags & DADD_EPI_ROWVEC) add += *reinterpret_cast<const f4*>(p.rowvec + (size_t)bsmp * p.ld_rowvec + n);
-    for (int r = rl; r < 64; r += RL) {
-      const int m = m_base + r;
-      const float* slab = p.partial + (size_t)m * p.N + n;
-      f4 v = add;
-      for (int s2 = 0; s2 < nsplit; ++s2) v += *reinterpret_cast<const f4*>(slab + (size_t)s2 * sstride);
+    f4 v[NR];
+    const float* slab[NR];
+    bool ok[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int r = rl + j * RL;
+      ok[j] = r < R;
+      slab[j] = p.partial + (size_t)(m_base + (ok[j] ? r : 0)) * p.N + n;
+      v[j] = add;
+    }
+    for (int s2 = 0; s2 < nsplit; s2 += 4) {        // NR rows x four slabs in flight, summed in slice order
+      f4 tt[NR][4];
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tt[j][u] = *reinterpret_cast<const f4*>(slab[j] + (size_t)min(s2 + u, nsplit - 1) * sstride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float keep = (s2 + u < nsplit) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = fmaf(keep, tt[j][u][e], v[j][e]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      if (!ok[j]) continue;
+      const int m = m_base + rl + j * RL;
       if (p.flags & DADD_EPI_RESIDUAL) {
         const h4 rv = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        for (int e = 0; e < 4; ++e) v[j][e] += (float)rv[e];
       }
       h4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o[e] = (half_t)v[e];
+        o[e] = (half_t)v[j][e];
         const float f = (float)o[e];
         cs[e] += f;
         cq[e] = fmaf(f, f, cq[e]);
@@ -291,7 +319,7 @@ __global__ __launch_bounds__(256) void splitk_finish_gn_kernel(const IgemmArgs p
         a += red[r][t * p.gn_cg + c][0];
         qq += red[r][t * p.gn_cg + c][1];
       }
-    const int chunk = (m_base - bsmp * HoWo) / 64;
+    const int chunk = (m_base - bsmp * HoWo) / R;
     float* w = p.gn_ws + (((size_t)bsmp * p.gn_nchunk + chunk) * 32 + (blockIdx.y * CB) / p.gn_cg + t) * 2;
     w[0] = a;
     w[1] = qq;
@@ -473,13 +501,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     DADD_REQUIRE(halo_ns == 1 || a.partial != nullptr, "igemm: split-K needs a partial buffer");
   }
   if ((a.flags & DADD_EPI_GNSTAT) && (halo ? halo_ns : nsplit) > 1) {
-    // split-K: the finish kernel writes the partials, per 64-row chunk and 160- (or 128-) column block of whole groups
+    // split-K: the finish kernel writes the partials, per chunk of 16 (or 64) rows and 160- (or 128-) column block of whole groups
     const int cb = (a.N % 160 == 0) ? 160 : 128, howo = a.Ho * a.Wo;
+    const int rows = a.gn_nchunk > 0 ? howo / a.gn_nchunk : 0;
     DADD_REQUIRE(a.gn_ws && a.gn_cg > 0 && a.N == 32 * a.gn_cg && !geglu && a.counters == nullptr && a.N % cb == 0 &&
-                     cb % a.gn_cg == 0 && a.M % 64 == 0 && howo % 64 == 0 && a.gn_nchunk == howo / 64 &&
-                     !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
+                     cb % a.gn_cg == 0 && (rows == 16 || rows == 64) && a.M % rows == 0 && howo % rows == 0 &&
+                     a.gn_nchunk * rows == howo && !(a.flags & (DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK)),
                  "igemm: GroupNorm statistics with split-K need the finish kernel (no tickets), N == 32 groups in blocks of "
-                 "160 / 128 columns, Ho*Wo %% 64 == 0 and gn_nchunk == Ho*Wo / 64");
+                 "160 / 128 columns, and chunks of 16 or 64 rows: gn_nchunk == Ho*Wo / 16 (or / 64)");
   } else if (a.flags & DADD_EPI_GNSTAT) {
     const int wm_rows = tile_m / 2, wn_cols = tile_n / 2, howo = a.Ho * a.Wo;
     DADD_REQUIRE(a.gn_ws && a.gn_cg > 0 && a.N == 32 * a.gn_cg && !geglu && (tile_n == 128 || tile_n == 160) &&
@@ -529,10 +558,16 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                                (double)a.M * a.N * (4.0 * ns + 2.0 + ((a.flags & DADD_EPI_RESIDUAL) ? 2.0 : 0.0))};
     if (!(a.flags & DADD_EPI_GNSTAT))
       dadd_launch(tag, splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, ns);
-    else if (a.N % 160 == 0)
-      dadd_launch(tag, splitk_finish_gn_kernel<160>, dim3(a.M / 64, a.N / 160), dim3(256), 0, s, a, ns);
-    else
-      dadd_launch(tag, splitk_finish_gn_kernel<128>, dim3(a.M / 64, a.N / 128), dim3(256), 0, s, a, ns);
+    else {
+      const int rows = (a.Ho * a.Wo) / a.gn_nchunk;
+      if (a.N % 160 == 0) {
+        if (rows == 16) dadd_launch(tag, splitk_finish_gn_kernel<160, 16>, dim3(a.M / 16, a.N / 160), dim3(256), 0, s, a, ns);
+        else dadd_launch(tag, splitk_finish_gn_kernel<160, 64>, dim3(a.M / 64, a.N / 160), dim3(256), 0, s, a, ns);
+      } else {
+        if (rows == 16) dadd_launch(tag, splitk_finish_gn_kernel<128, 16>, dim3(a.M / 16, a.N / 128), dim3(256), 0, s, a, ns);
+        else dadd_launch(tag, splitk_finish_gn_kernel<128, 64>, dim3(a.M / 64, a.N / 128), dim3(256), 0, s, a, ns);
+      }
+    }
     DADD_LAUNCH_CHECK();
   }
   return DADD_OK;

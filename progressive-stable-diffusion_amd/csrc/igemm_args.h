@@ -101,10 +101,8 @@ __device__ __forceinline__ void ln_finish(float (&s1)[MI], float (&s2)[MI], int 
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float a = s1[i], q = s2[i];
-    a += __shfl_xor(a, 16, 64);
-    q += __shfl_xor(q, 16, 64);
-    a += __shfl_xor(a, 32, 64);
-    q += __shfl_xor(q, 32, 64);
+    a = dadd_sum_x16x32(a);
+    q = dadd_sum_x16x32(q);
     const float mu = a * inv;
     const float var = fmaxf(q * inv - mu * mu, 0.f);
     s1[i] = mu;

@@ -397,10 +397,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& p, f4 (&acc)[J][
       *reinterpret_cast<h4*>(p.out + (size_t)m * p.ldo + n) = o;
     }
     if (lnstat) {     // wave-uniform.  The four lanes (lane & 15) + 16 g hold the WN columns of row m between them.
-      rs1 += __shfl_xor(rs1, 16, 64);
-      rs2 += __shfl_xor(rs2, 16, 64);
-      rs1 += __shfl_xor(rs1, 32, 64);
-      rs2 += __shfl_xor(rs2, 32, 64);
+      rs1 = dadd_sum_x16x32(rs1);
+      rs2 = dadd_sum_x16x32(rs2);
       if (g == 0) {
         const int part = (n0 + wn * WN) / WN;
         reinterpret_cast<dadd_f2*>(p.ln_stats_out)[(size_t)part * p.M + m] = dadd_f2{rs1, rs2};

@@ -152,6 +152,7 @@ HALO_DUO = False
 # GroupNorm statistics written by the producing GEMM's epilogue (no gn_stats launch, one read of the tensor less).
 GN_FROM_EPILOGUE = True
 GN_FUSED_MAX_BYTES = 16 * 1024       # csrc/norm.hip: below this slab size the single-launch LDS GroupNorm runs
+SPLITK_GN_ROWS = 16                  # rows per block / per GroupNorm chunk of splitk_finish_gn_kernel (16 or 64)
 
 
 # LayerNorm folded into the consuming linear (qkv, attn2.to_q, GEGLU projection) instead of a LayerNorm launch and a
@@ -355,9 +356,10 @@ class _Plan:
             if sk == 1:     # the GEMM's own epilogue writes the partials: one chunk per MFMA wave's row block
                 wm_rows = tile_m // 2
                 ok = tile_n in (128, 160) and (tile_n // 2) % cg == 0 and m % tile_m == 0 and n % tile_n == 0
-            else:           # split-K: the finish kernel writes them, per 64 rows x 160 (128) columns
-                wm_rows, cb = 64, (160 if n % 160 == 0 else 128)
-                ok = n % cb == 0 and cb % cg == 0 and m % 64 == 0
+            else:           # split-K: the finish kernel writes them, per 16 rows x 160 (128) columns
+                wm_rows = SPLITK_GN_ROWS if howo // SPLITK_GN_ROWS <= 128 else 64      # (<= 128 chunks keeps GroupNorm-in-conv eligible)
+                cb = 160 if n % 160 == 0 else 128
+                ok = n % cb == 0 and cb % cg == 0 and m % wm_rows == 0
             nchunk = howo // wm_rows
             # (maps whose (batch, group) slab fits the single-launch LDS GroupNorm keep that path)
             # (> 128 chunks — the VAE maps — are folded to 64 per sample by gn_reduce_kernel inside dadd_groupnorm_f16:

@@ -921,21 +921,25 @@ def test_igemm_groupnorm_statistics_epilogue(hip, case):
     hip.groupnorm(o, None, dev(hip, gamma), dev(hip, beta), y2, ws2, 32, 1e-5, 1)
     hip.synchronize()
     close(y1, y2.float().cpu(), 2e-3, 2e-3, f"gn from partials {case}")
-    # split-K: the finish kernel writes the partials (64-row chunks, blocks of 160 / 128 columns)
-    nch2 = hw * hw // 64
-    ws3 = hip.zeros((b * nch2 * 64,), F32)
-    o3 = hip.zeros((b, hw, hw, n), F16)
-    hip.igemm(dev(hip, x), dev(hip, w), o3, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=taps,
-              pad=taps // 9, flags=7 | L.EPI_GNSTAT | (tune & ~L.TUNE_NODMA), tile_m=tm, tile_n=tn, gn_ws=ws3, gn_nchunk=nch2,
-              splitk=2, partial=hip.zeros((2 * b * hw * hw * n,), F32))
-    y3 = hip.zeros((b, hw, hw, n), F16)
-    hip.groupnorm(o3, None, dev(hip, gamma), dev(hip, beta), y3, ws3, 32, 1e-5, 1, ws_chunks=nch2)
-    hip.synchronize()
-    close(o3, o_ref, 3e-3, 2e-3, f"gnstat split-K out {case}")
-    oc3 = o3.float().cpu().reshape(b, nch2, -1, 32, n // 32)
-    part3 = torch.stack([oc3.sum(dim=(2, 4)), (oc3 * oc3).sum(dim=(2, 4))], dim=-1)
-    assert (ws3.cpu().reshape(b, nch2, 32, 2) - part3).abs().max().item() <= 1e-3 * part3.abs().max().item() + 1e-3
-    close(y3, y2.float().cpu(), 3e-3, 3e-3, f"gn from finish partials {case}")
+    # split-K: the finish kernel writes the partials (chunks of 16 rows — the engine's choice — or 64, blocks of 160 / 128
+    # columns; three slices: the four-slabs-in-flight loop with a clamped tail)
+    for rows, sk in ((16, 3), (64, 2)):
+        if case == "halo64" and rows == 16:      # one 64-channel chunk: the halo conv cannot split K, its own epilogue
+            continue                             # writes the partials (64-row chunks)
+        nch2 = hw * hw // rows
+        ws3 = hip.zeros((b * (nch2 + 64) * 64,), F32)         # (+ room for the fold of > 128 chunks to 64)
+        o3 = hip.zeros((b, hw, hw, n), F16)
+        hip.igemm(dev(hip, x), dev(hip, w), o3, bias=dev(hip, bias), rowvec=dev(hip, rowvec), residual=dev(hip, res), taps=taps,
+                  pad=taps // 9, flags=7 | L.EPI_GNSTAT | (tune & ~L.TUNE_NODMA), tile_m=tm, tile_n=tn, gn_ws=ws3, gn_nchunk=nch2,
+                  splitk=sk, partial=hip.zeros((sk * b * hw * hw * n,), F32))
+        y3 = hip.zeros((b, hw, hw, n), F16)
+        hip.groupnorm(o3, None, dev(hip, gamma), dev(hip, beta), y3, ws3, 32, 1e-5, 1, ws_chunks=nch2)
+        hip.synchronize()
+        close(o3, o_ref, 3e-3, 2e-3, f"gnstat split-K out {case} rows {rows}")
+        oc3 = o3.float().cpu().reshape(b, nch2, -1, 32, n // 32)
+        part3 = torch.stack([oc3.sum(dim=(2, 4)), (oc3 * oc3).sum(dim=(2, 4))], dim=-1)
+        assert (ws3.cpu()[:b * nch2 * 64].reshape(b, nch2, 32, 2) - part3).abs().max().item() <= 1e-3 * part3.abs().max().item() + 1e-3
+        close(y3, y2.float().cpu(), 3e-3, 3e-3, f"gn from finish partials {case} rows {rows}")
     if case == "dma128x128":               # many chunks (VAE maps): folded to 64 per sample by gn_reduce_kernel first
         nbig = 320
         noise = torch.randn(b, nbig, 32, 2, generator=torch.Generator().manual_seed(5)) * 0.01
