@@ -52,6 +52,13 @@ extern "C" {
 #define DADD_EPI_GNSTAT 2048 /* the epilogue also writes the GroupNorm chunk partials of its OUTPUT (32 groups) into
                                gn_ws [B][gn_nchunk][32][2] (sum, sum of squares per row block of tile_m/2 rows): the
                                consuming dadd_groupnorm_f16 then skips its statistics pass (ws_chunks = gn_nchunk) */
+#define DADD_EPI_GNAPPLY 32768 /* split-K launches on small maps (Ho*Wo * N/32 * 2 bytes <= 16 KiB per (sample, group) slab, finish
+                                kernel, no GEGLU / GNSTAT): the finish kernel owns one (sample, group) per block, so it also writes
+                                GroupNorm(out) (+ SiLU with DADD_EPI_GNAPPLY_SILU) into gn_out [M][N] with gn_out_gamma / _beta /
+                                _eps - the next conv's input - instead of a GroupNorm launch over `out`.  `out` itself is still
+                                written (residual / skip consumers).  Same arithmetic, in the same order, as the finish kernel
+                                followed by dadd_groupnorm_f16's single-launch path: bit-identical results */
+#define DADD_EPI_GNAPPLY_SILU 65536
 #define DADD_EPI_QUICKGELU 256 /* x * sigmoid(1.702 x) after bias (CLIP MLP, transformers quick_gelu) */
 #define DADD_EPI_GELU 512      /* exact-form GELU after bias (nn.GELU of the resampler / purifier MLPs) */
 #define DADD_EPI_SIGMOID 1024  /* sigmoid after bias (FeaturePurifier gate) */
@@ -118,6 +125,10 @@ typedef struct {
   const float* gn_in_ws2;        /* DADD_PRE_GN over the concatenation [x | x2]: the chunk partials of x2 (its own 32 groups over
                                     C2 channels); needs (C1 + C2) / 32 to be a multiple of C1 / 32 and of C2 / 32 and to divide C1 */
   int32_t gn_in_nchunk2;
+  void* gn_out;                  /* DADD_EPI_GNAPPLY (see the flag): fp16 [M][N] */
+  const float* gn_out_gamma;
+  const float* gn_out_beta;
+  float gn_out_eps;
 } dadd_igemm_desc;
 int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream);
 
@@ -130,9 +141,12 @@ int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* bias, void*
                           int W, int Cout, void* stream);
 /* conv_in of the UNet in one launch: fp32 NCHW latents (C <= 4 channels, rounded to fp16 in registers exactly as
  * dadd_pack_nchw_f32_to_nhwc8_f16 with scale 1 does) -> fp16 NHWC Cout; w is the [Cout][9][8] layout of conv_cin8.
- * Replaces UNet2DConditionModel.conv_in behind OrdinalUNet.forward (src/models/unet/unet.py:140-144). */
+ * Replaces UNet2DConditionModel.conv_in behind OrdinalUNet.forward (src/models/unet/unet.py:140-144).
+ * gn_ws != NULL (Cout == 320, H*W a multiple of 256, gn_nchunk == H*W/256): also writes the GroupNorm chunk partials
+ * [B][gn_nchunk][32][2] (sum, sum of squares of the rounded outputs, 256 pixels per chunk) that dadd_groupnorm_f16
+ * (ws_chunks), DADD_PRE_GN and dadd_tf_head_f16 consume - the first ResNet's norm1 needs no statistics pass. */
 int dadd_conv_in_nchw_f16(const float* x_nchw, const void* w, const float* bias, void* out, int B, int C,
-                          int H, int W, int Cout, void* stream);
+                          int H, int W, int Cout, float* gn_ws, int gn_nchunk, void* stream);
 int dadd_conv3x3_cout4_f16(const void* x, const void* w, const float* bias, float* out_nchw, int B,
                            int H, int W, int C, int Cout, int mode, void* stream);
 /* conv_out of the UNet fused with the deterministic DDIM update of the sampler (no CFG): eps = conv3x3(x) + bias is

@@ -111,11 +111,14 @@ class HipBackend:
         L.check(self.lib.dadd_conv3x3_cin8_f16(_p(x), _p(w), _p(bias), _p(out), b, h, wd, w.shape[0],
                                                self.s))
 
-    def conv_in_nchw(self, x, w, bias, out):
-        """fp32 NCHW latents (<= 4 channels) -> fp16 NHWC: pack_latents + conv_cin8 in one launch."""
+    def conv_in_nchw(self, x, w, bias, out, gn_ws=None, gn_nchunk=0):
+        """fp32 NCHW latents (<= 4 channels) -> fp16 NHWC: pack_latents + conv_cin8 in one launch; with ``gn_ws`` also
+        the GroupNorm chunk partials of the output (256 pixels per chunk)."""
         b, c, h, wd = x.shape
         assert x.dtype == torch.float32 and c <= 4 and w.shape[1:] == (9, 8) and out.shape == (b, h, wd, w.shape[0])
-        L.check(self.lib.dadd_conv_in_nchw_f16(_p(x), _p(w), _p(bias), _p(out), b, c, h, wd, w.shape[0], self.s))
+        assert gn_ws is None or (gn_ws.dtype == torch.float32 and gn_ws.numel() >= b * gn_nchunk * 64)
+        L.check(self.lib.dadd_conv_in_nchw_f16(_p(x), _p(w), _p(bias), _p(out), b, c, h, wd, w.shape[0],
+                                               _p(gn_ws), gn_nchunk, self.s))
 
     def conv_cout4(self, x, w, bias, out, mode=0):
         b, h, wd, c = x.shape
@@ -155,8 +158,10 @@ class HipBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None, gn_apply=None):
         """x [B,Hi,Wi,C1] (x2 [B,Hi,Wi,C2]); w [N, taps*(C1+C2)]; out [B,Ho,Wo,N] (N/2 for GEGLU).
+        ``gn_apply`` = (normalised output [B,Ho,Wo,N], gamma, beta, eps) with EPI_GNAPPLY: the split-K finish kernel also
+        writes GroupNorm(out) (+ SiLU with EPI_GNAPPLY_SILU).
         ``gn_in`` = (partials [B*nchunk*64] fp32, nchunk, gamma, beta, eps) with PRE_GN: GroupNorm of x on the way in.
         ``ln_stats_out`` [P][M][2] fp32 (EPI_LNSTAT): row partials of the output, P = N / (tile_n/2);
         ``ln_stats_in`` [P'][M][2] (EPI_LNFOLD): the partials of x written by its producer."""
@@ -203,6 +208,13 @@ class HipBackend:
                 ws2, nch2 = gn_in[5], gn_in[6]
                 assert x2 is not None and ws2.dtype == torch.float32 and ws2.numel() >= b * nch2 * 64
                 d.gn_in_ws2, d.gn_in_nchunk2 = _p(ws2), int(nch2)
+        d.gn_out = d.gn_out_gamma = d.gn_out_beta = None
+        d.gn_out_eps = 0.0
+        if gn_apply is not None:
+            g_out, gam, bet, eps_o = gn_apply
+            assert flags & L.EPI_GNAPPLY and g_out.shape == out.shape and g_out.dtype == torch.float16 and g_out.is_contiguous() \
+                and gam.dtype == bet.dtype == torch.float32 and gam.numel() == n and bet.numel() == n
+            d.gn_out, d.gn_out_gamma, d.gn_out_beta, d.gn_out_eps = _p(g_out), _p(gam), _p(bet), float(eps_o)
         if partial is not None:
             assert partial.numel() >= splitk * b * ho * wo * n
         L.check(self.lib.dadd_conv_igemm_f16(C.byref(d), self.s))

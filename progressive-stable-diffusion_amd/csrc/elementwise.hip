@@ -110,6 +110,72 @@ __global__ __launch_bounds__(256) void conv_in_nchw_kernel(const float* __restri
   *reinterpret_cast<h8*>(out + (size_t)pix * Cout + co0) = r;
 }
 
+// The same conv with the GroupNorm chunk partials of its output (the first ResNet's norm1 and the last up block's
+// skip-concat then need no statistics pass and can normalise inside their 3x3 conv): a block owns 256 pixels (one chunk)
+// and FOUR whole groups (4 * CG channels, eight at a time), every thread sums its pixel's rounded outputs per group, the
+// block reduces them in a fixed order (butterfly per wave, then the four waves) and writes [b][chunk][group](sum, sum of
+// squares).  grid (B*HW / 256, Cout / (4*CG)); HW % 256 == 0 so that a chunk never straddles two samples.
+template <int CG>
+__global__ __launch_bounds__(256) void conv_in_nchw_gn_kernel(const float* __restrict__ x, const half_t* __restrict__ w,
+                                                              const float* __restrict__ bias, half_t* __restrict__ out,
+                                                              float* __restrict__ gn_ws, int B, int C, int H, int W, int Cout) {
+  typedef _Float16 ci_h2 __attribute__((ext_vector_type(2)));
+  static_assert((4 * CG) % 8 == 0, "four groups must be whole 8-channel stores");
+  __shared__ float red[4][8];
+  const int HW = H * W;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int co0 = blockIdx.y * 4 * CG;
+  const int b = pix / HW, rem = pix - b * HW, oy = rem / W, ox = rem - oy * W;
+  ci_h2 x01[9], x23[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float* xp = x + (size_t)b * C * HW + (ok ? iy * W + ix : rem);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (c < C && ok) ? xp[(size_t)c * HW] : 0.f;
+    x01[tap] = ci_h2{(_Float16)v[0], (_Float16)v[1]};
+    x23[tap] = ci_h2{(_Float16)v[2], (_Float16)v[3]};
+  }
+  float st[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // (sum, sum of squares) of the four groups
+#pragma unroll
+  for (int o8 = 0; o8 < 4 * CG / 8; ++o8) {
+    h8 r;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int co = co0 + o8 * 8 + o;
+      float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const h4 wv = *reinterpret_cast<const h4*>(w + ((size_t)co * 9 + tap) * 8);
+        acc = __builtin_amdgcn_fdot2(x01[tap], ci_h2{wv[0], wv[1]}, acc, false);
+        acc = __builtin_amdgcn_fdot2(x23[tap], ci_h2{wv[2], wv[3]}, acc, false);
+      }
+      r[o] = (half_t)acc;
+      const float f = (float)r[o];
+      const int g = (o8 * 8 + o) / CG;      // compile-time after unrolling
+      st[2 * g] += f;
+      st[2 * g + 1] += f * f;
+    }
+    *reinterpret_cast<h8*>(out + (size_t)pix * Cout + co0 + o8 * 8) = r;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st[i] = wave_sum(st[i]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wave][i] = st[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x;
+    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    const int chunk = (blockIdx.x * 256 - b * HW) >> 8, nchunk = HW >> 8;
+    gn_ws[(((size_t)b * nchunk + chunk) * 32 + blockIdx.y * 4 + (i >> 1)) * 2 + (i & 1)] = v;
+  }
+}
+
 // conv3x3 pad1 to <=4 output channels, fp32 NCHW output.  16 lanes share a pixel (channel chunks of 8 strided over the
 // 16 lanes -> 256 contiguous bytes per tap) and every thread carries TWO pixels 16 apart, so one weight fragment read
 // from LDS serves both; the nine taps of a chunk are loaded back to back (18 independent 16-byte loads in flight per
@@ -486,12 +552,22 @@ extern "C" int dadd_conv3x3_cin8_f16(const void* x, const void* w, const float* 
 }
 
 extern "C" int dadd_conv_in_nchw_f16(const float* x_nchw, const void* w, const float* bias, void* out, int B, int C,
-                                    int H, int W, int Cout, void* stream) {
+                                    int H, int W, int Cout, float* gn_ws, int gn_nchunk, void* stream) {
   DADD_REQUIRE(x_nchw && w && out, "conv_in_nchw: null pointer");
   DADD_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 1 && C <= 4 && Cout > 0 && Cout % 8 == 0,
                "conv_in_nchw: C must be 1..4 and Cout a multiple of 8");
   DADD_REQUIRE(dadd_aligned16(w) && dadd_aligned16(out), "conv_in_nchw: w / out must be 16-byte aligned");
   const int npix = B * H * W;
+  if (gn_ws != nullptr) {     // GroupNorm chunk partials of the output: [B][gn_nchunk][32][2], 256 pixels per chunk
+    DADD_REQUIRE(Cout == 320 && (H * W) % 256 == 0 && gn_nchunk == (H * W) / 256 && gn_nchunk <= DADD_GN_MAX_CHUNKS,
+                 "conv_in_nchw: GroupNorm partials need Cout == 320, H*W %% 256 == 0 and gn_nchunk == H*W/256 (<= %d)",
+                 DADD_GN_MAX_CHUNKS);
+    dadd_launch({"conv_in_nchw_gn_kernel", 2.0 * npix * Cout * 9.0 * C, (double)npix * (4.0 * C + 2.0 * Cout)},
+                conv_in_nchw_gn_kernel<10>, dim3(npix / 256, Cout / 40), dim3(256), 0, static_cast<hipStream_t>(stream),
+                x_nchw, static_cast<const half_t*>(w), bias, static_cast<half_t*>(out), gn_ws, B, C, H, W, Cout);
+    DADD_LAUNCH_CHECK();
+    return DADD_OK;
+  }
   dadd_launch({"conv_in_nchw_kernel", 2.0 * npix * Cout * 9.0 * C, (double)npix * (4.0 * C + 2.0 * Cout)}, conv_in_nchw_kernel,
               dim3((npix + 255) / 256, Cout / 8), dim3(256), 0, static_cast<hipStream_t>(stream), x_nchw,
               static_cast<const half_t*>(w), bias, static_cast<half_t*>(out), B, C, H, W, Cout);

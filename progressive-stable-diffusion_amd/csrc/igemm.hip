@@ -326,6 +326,96 @@ __global__ __launch_bounds__(256) void splitk_finish_gn_kernel(const IgemmArgs p
   }
 }
 
+// Finish of a split-K launch on a small map whose output feeds a GroupNorm (DADD_EPI_GNAPPLY): one block per (group,
+// sample) sums the slabs of its Ho*Wo x cg slab (the finish kernel's order: slices, bias, rowvec, residual; one rounding),
+// writes it, keeps it in LDS, reduces (the single-launch GroupNorm's order: per-thread strided pairs, wave butterfly, four
+// waves in double) and writes the normalised (+ SiLU) copy the next conv reads.  Replaces splitk_finish_kernel +
+// gn_fused_kernel on the 8x8 maps (two launches of ~5 us each for 0.6 MB) with bit-identical results.
+template <int VEC>
+__global__ __launch_bounds__(512) void splitk_finish_gnapply_kernel(const IgemmArgs p, int nsplit) {
+  typedef float fv __attribute__((ext_vector_type(VEC)));
+  typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+  extern __shared__ __attribute__((aligned(16))) char fg_smem[];
+  half_t* slab = reinterpret_cast<half_t*>(fg_smem);       // [HW][cg]
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int HW = p.Ho * p.Wo, cg = p.N >> 5, hp = cg >> 1, c0 = g * cg, npair = HW * hp;
+  const int vp = cg / VEC, nitem = HW * vp;
+  const size_t sstride = (size_t)p.M * p.N;
+  // 1. the finish: every item (row, VEC channels) with eight slabs in flight, summed in slice order
+  for (int idx = t; idx < nitem; idx += 512) {
+    const int row = idx / vp, cv = idx - row * vp;
+    const int c = c0 + VEC * cv;
+    const size_t m = (size_t)b * HW + row;
+    const float* sl = p.partial + m * p.N + c;
+    fv v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    for (int k0 = 0; k0 < nsplit; k0 += 8) {
+      fv tt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tt[u] = *reinterpret_cast<const fv*>(sl + (size_t)min(k0 + u, nsplit - 1) * sstride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float keep = (k0 + u < nsplit) ? 1.f : 0.f;      // fma(1, t, v) == v + t: the finish kernel's sums exactly
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = fmaf(keep, tt[u][e], v[e]);
+      }
+    }
+    if (p.flags & DADD_EPI_BIAS) v += *reinterpret_cast<const fv*>(p.bias + c);
+    if (p.flags & DADD_EPI_ROWVEC) v += *reinterpret_cast<const fv*>(p.rowvec + (size_t)b * p.ld_rowvec + c);
+    if (p.flags & DADD_EPI_RESIDUAL) {
+      const hv rv = *reinterpret_cast<const hv*>(p.residual + m * p.ldr + c);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += (float)rv[e];
+    }
+    hv o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = (half_t)v[e];
+    *reinterpret_cast<hv*>(p.out + m * p.ldo + c) = o;
+    *reinterpret_cast<hv*>(slab + row * cg + VEC * cv) = o;
+  }
+  __syncthreads();
+  // 2. the statistics, in the single-launch GroupNorm's order: 256 strided lanes of channel pairs, butterfly, four waves
+  float s = 0.f, ss = 0.f;
+  if (t < 256) {
+    for (int idx = t; idx < npair; idx += 256) {
+      const h2 v = *reinterpret_cast<const h2*>(slab + 2 * idx);
+      const float a = (float)v[0], d = (float)v[1];
+      s += a + d;
+      ss += a * a + d * d;
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+  }
+  __syncthreads();
+  const double n = (double)HW * (double)cg;
+  const double sum = (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3];
+  const double sq = (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3];
+  const double mu = sum / n;
+  double var = sq / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + (double)p.gno_eps));
+  const bool silu = (p.flags & DADD_EPI_GNAPPLY_SILU) != 0;
+  // 3. normalise from LDS
+  for (int idx = t; idx < npair; idx += 512) {
+    const int row = idx / hp, cp = idx - row * hp;
+    const int c = c0 + 2 * cp;
+    const h2 v = *reinterpret_cast<const h2*>(slab + 2 * idx);
+    h2 o;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float sc = rstd * p.gno_gamma[c + e];
+      float f = ((float)v[e] - mean) * sc + p.gno_beta[c + e];
+      if (silu) f = dadd_silu(f);
+      o[e] = (half_t)f;
+    }
+    *reinterpret_cast<h2*>(p.gno_out + ((size_t)b * HW + row) * p.N + c) = o;
+  }
+}
+
 template <int BM, int BN, bool DEEP>
 int set_attr() {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + (BM == 128 ? (BN == 160 ? 8192 : LN_LDS_BYTES) : 4096);
@@ -382,7 +472,11 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
   a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N;
   a.taps = d->taps; a.stride = d->stride; a.ups = d->ups; a.pad = d->pad;
   a.flags = d->flags & (15 | DADD_TUNE_PERSIST | DADD_EPI_LNFOLD | DADD_EPI_ACT_MASK | DADD_EPI_GNSTAT | DADD_EPI_LNSTAT |
-                        DADD_PRE_GN | DADD_PRE_GN_SILU);
+                        DADD_PRE_GN | DADD_PRE_GN_SILU | DADD_EPI_GNAPPLY | DADD_EPI_GNAPPLY_SILU);
+  a.gno_out = static_cast<half_t*>(d->gn_out);
+  a.gno_gamma = d->gn_out_gamma;
+  a.gno_beta = d->gn_out_beta;
+  a.gno_eps = d->gn_out_eps;
   a.gn_ws = d->gn_ws;
   a.gn_nchunk = d->gn_nchunk;
   a.gn_cg = d->gn_cg;   // epilogue bits + the persistent-ring request
@@ -517,6 +611,16 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
                  "igemm: GroupNorm statistics need full tiles of 128/160 columns holding whole groups, whole-wave row blocks "
                  "inside one sample (Ho*Wo %% %d == 0, gn_nchunk == Ho*Wo / %d), N == 32 groups, no split-K", wm_rows, wm_rows);
   }
+  if (a.flags & DADD_EPI_GNAPPLY) {
+    DADD_REQUIRE((halo ? halo_ns : nsplit) > 1 && a.counters == nullptr && a.gno_out && a.gno_gamma && a.gno_beta &&
+                     a.gno_eps > 0.f && a.N % 64 == 0 && a.ldo % 2 == 0 && a.ldr % 2 == 0 &&
+                     (size_t)a.Ho * a.Wo * (a.N / 32) * 2 <= 16 * 1024 && dadd_aligned16(a.gno_out) &&
+                     !(a.flags & (DADD_EPI_GNSTAT | DADD_EPI_LNFOLD | DADD_EPI_LNSTAT | DADD_EPI_ACT_MASK)),
+                 "igemm: GroupNorm of the output in the finish kernel needs a finish-kernel split-K launch, gn_out / gamma / "
+                 "beta / eps, N %% 64 == 0, a (sample, group) slab of <= 16 KiB and no other statistics / activation flags");
+  } else {
+    DADD_REQUIRE(!(a.flags & DADD_EPI_GNAPPLY_SILU), "igemm: DADD_EPI_GNAPPLY_SILU without DADD_EPI_GNAPPLY");
+  }
   if (a.flags & DADD_EPI_LNSTAT) {
     const int wn_cols = tile_n / 2;
     DADD_REQUIRE(a.ln_stats_out && !geglu && !halo && a.N % wn_cols == 0 && d->ln_parts_out == a.N / wn_cols &&
@@ -556,7 +660,14 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     const int ns = halo ? halo_ns : nsplit;
     const DaddLaunchTag tag = {(a.flags & DADD_EPI_GNSTAT) ? "splitk_finish_gn_kernel" : "splitk_finish_kernel", 0.0,
                                (double)a.M * a.N * (4.0 * ns + 2.0 + ((a.flags & DADD_EPI_RESIDUAL) ? 2.0 : 0.0))};
-    if (!(a.flags & DADD_EPI_GNSTAT))
+    if (a.flags & DADD_EPI_GNAPPLY) {
+      const DaddLaunchTag tag2 = {"splitk_finish_gnapply_kernel", 0.0, tag.bytes + 2.0 * a.M * a.N};
+      const unsigned slab_bytes = (unsigned)(a.Ho * a.Wo * (a.N / 32) * 2);
+      if ((a.N / 32) % 4 == 0 && a.ldo % 4 == 0 && a.ldr % 4 == 0 && a.ld_rowvec % 4 == 0)
+        dadd_launch(tag2, splitk_finish_gnapply_kernel<4>, dim3(32, a.B), dim3(512), slab_bytes, s, a, ns);
+      else
+        dadd_launch(tag2, splitk_finish_gnapply_kernel<2>, dim3(32, a.B), dim3(512), slab_bytes, s, a, ns);
+    } else if (!(a.flags & DADD_EPI_GNSTAT))
       dadd_launch(tag, splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a, ns);
     else {
       const int rows = (a.Ho * a.Wo) / a.gn_nchunk;

@@ -26,6 +26,10 @@ struct IgemmArgs {
   float gni_eps;
   const float* gni_ws2;       // ... of the second source (skip-concat): its own 32 groups over C2 channels
   int gni_nchunk2;
+  half_t* gno_out;            // DADD_EPI_GNAPPLY: GroupNorm (+ SiLU) of the OUTPUT written beside it by the split-K finish
+  const float* gno_gamma;
+  const float* gno_beta;
+  float gno_eps;
   int B, Hi, Wi, C1, C2, Ho, Wo, N;
   int taps, stride, ups, pad;
   int ldo, ldr, ld_rowvec;

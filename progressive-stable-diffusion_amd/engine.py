@@ -149,6 +149,10 @@ GN_IN_CONV = True
 # (profiles/r02_zn_halo_duo_ab.txt), so off; True is the A/B switch
 HALO_DUO = False
 
+# On the 8x8 maps the split-K finish kernel of a conv also writes the GroupNorm (+ SiLU) of its output for the next conv
+# (DADD_EPI_GNAPPLY, csrc/igemm.hip splitk_finish_gnapply_kernel): one launch instead of finish + single-launch GroupNorm
+FINISH_GN_APPLY = True
+
 # GroupNorm statistics written by the producing GEMM's epilogue (no gn_stats launch, one read of the tensor less).
 GN_FROM_EPILOGUE = True
 GN_FUSED_MAX_BYTES = 16 * 1024       # csrc/norm.hip: below this slab size the single-launch LDS GroupNorm runs
@@ -294,9 +298,13 @@ class _Plan:
         self.gn_partials: Dict[int, Tuple[torch.Tensor, int]] = {}   # output buffer -> (chunk partials, chunks)
         self.ln_partials: Dict[int, torch.Tensor] = {}               # output buffer -> LayerNorm row partials [P][M][2]
 
+        self._memo: Dict = {}
+        self.gn_ready: Dict[int, Tuple] = {}      # output buffer -> (its GroupNorm written by the finish kernel, gamma, beta, eps, silu)
+
         def _forget(t):                 # a recycled buffer loses its statistics
             self.gn_partials.pop(t.data_ptr(), None)
             self.ln_partials.pop(t.data_ptr(), None)
+            self.gn_ready.pop(t.data_ptr(), None)
         self.pool.on_put = _forget
         self.gn_ws = None
         # Split-K slabs are combined by the finish kernel.  The in-launch combine (last-arriving slice
@@ -320,8 +328,11 @@ class _Plan:
     def cached(self, key, make):
         """Device tensor for ``key`` from the optional cross-plan cache (``wcache``: plans for other batch sizes
         or tilings over the same state dict share the packed weights instead of re-packing 1.9 GB each)."""
-        if self.wcache is None:
-            return make()
+        if self.wcache is None:         # plan-local memo: one device copy per key (fuse_gn hints name the same tensors twice)
+            t = self._memo.get(key)
+            if t is None:
+                t = self._memo[key] = make()
+            return t
         t = self.wcache.get(key)
         if t is None:
             t = self.wcache[key] = make()
@@ -332,8 +343,11 @@ class _Plan:
     # ---- recorded building blocks -----------------------------------------------------------
     def conv(self, x, w, out_shape, *, x2=None, bias=None, rowvec=None, residual=None, taps=9,
              stride=1, ups=0, pad=1, flags=0, ln_c1=None, ln_eps=1e-5, gn_stats=False, ln_stats=False,
-             ln_stats_in=None, gn_in=None):
+             ln_stats_in=None, gn_in=None, fuse_gn=None):
         """``gn_in`` = (partials, nchunk, gamma, beta, eps, silu): GroupNorm of ``x`` on the way in (``gn_in_conv_ok``).
+        ``fuse_gn`` = (gamma, beta, eps, silu) of the GroupNorm that consumes the output: on the small maps, where the
+        conv runs split-K and a (sample, group) slab is <= 16 KiB, the finish kernel writes the normalised copy too
+        (DADD_EPI_GNAPPLY) and the consuming ``gn()`` finds it in ``self.gn_ready`` instead of launching.
         ``ln_stats``: the output feeds a LayerNorm whose consumer is a folded linear — have the epilogue write the row
         partials (DADD_EPI_LNSTAT) where the launch allows (plain linear, one K pass, whole wave column blocks); they
         are found again through ``self.ln_partials``.  ``ln_stats_in``: such partials of ``x`` for this folded linear.
@@ -381,6 +395,12 @@ class _Plan:
         f = flags | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_ROWVEC if rowvec is not None else 0) \
             | (L.EPI_RESIDUAL if residual is not None else 0) | (L.EPI_LNFOLD if ln_c1 is not None else 0) | tune
         kw = dict(ln_c1=ln_c1, ln_eps=ln_eps) if ln_c1 is not None else {}
+        if (fuse_gn is not None and FINISH_GN_APPLY and sk > 1 and self.sk_counters is None and not (f & L.EPI_GNSTAT)
+                and n % 64 == 0 and out_shape[1] * out_shape[2] * (n // 32) * 2 <= GN_FUSED_MAX_BYTES):
+            g_out = self.pool.get(out_shape)
+            f |= L.EPI_GNAPPLY | (L.EPI_GNAPPLY_SILU if fuse_gn[3] else 0)
+            kw["gn_apply"] = (g_out, fuse_gn[0], fuse_gn[1], fuse_gn[2])
+            self.gn_ready[out.data_ptr()] = (g_out, fuse_gn[0].data_ptr(), fuse_gn[1].data_ptr(), float(fuse_gn[2]), bool(fuse_gn[3]))
         if gn_in is not None:       # (partials, chunks, gamma, beta, eps, silu[, partials of x2, chunks of x2])
             f |= L.PRE_GN | (L.PRE_GN_SILU if gn_in[5] else 0)
             kw["gn_in"] = tuple(gn_in[:5]) + tuple(gn_in[6:])
@@ -422,6 +442,10 @@ class _Plan:
 
     def gn(self, x1, x2, gamma, beta, eps, silu):
         c = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+        ready = self.gn_ready.get(x1.data_ptr()) if x2 is None else None
+        if ready is not None and ready[1:] == (gamma.data_ptr(), beta.data_ptr(), float(eps), bool(silu)):
+            del self.gn_ready[x1.data_ptr()]       # written by the producer's split-K finish (DADD_EPI_GNAPPLY)
+            return ready[0]
         out = self.pool.get((*x1.shape[:3], c))
         part = self.gn_partials.get(x1.data_ptr()) if x2 is None else None
         if part is not None:            # statistics already written by the producing epilogue
@@ -538,7 +562,12 @@ class UNetPlan(_Plan):
         return self.cached((self.prefix + key, "f32"), lambda: self.dev(self.sd[self.prefix + key].float()))
 
     # -- blocks ----------------------------------------------------------------------------------
-    def _resnet(self, name, x, skip=None):
+    def _gn_of(self, key, eps, silu):
+        """(gamma, beta, eps, silu) of the GroupNorm ``key`` — the ``fuse_gn`` hint of the conv that feeds it."""
+        return (self.f(key + ".weight"), self.f(key + ".bias"), eps, silu)
+
+    def _resnet(self, name, x, skip=None, next_gn=None):
+        """``next_gn``: the GroupNorm that consumes this block's output first (``_gn_of``), if the caller knows it."""
         b, h, w_, _ = x.shape
         cin = x.shape[-1] + (0 if skip is None else skip.shape[-1])
         cout = self.sd[self.prefix + name + ".conv1.weight"].shape[0]
@@ -547,12 +576,12 @@ class UNetPlan(_Plan):
         p1 = self.gn_in_conv_ok(x, skip, w1, (b, h, w_, cout), None)
         if p1 is not None:           # norm1 + SiLU inside conv1 (p1 carries the skip's partials too when there is one)
             h1 = self.conv(x, w1, (b, h, w_, cout), x2=skip, bias=self.f(name + ".conv1.bias"),
-                           rowvec=self.temb_rows[:, off:off + cout], gn_stats=True,
+                           rowvec=self.temb_rows[:, off:off + cout], gn_stats=True, fuse_gn=self._gn_of(name + ".norm2", 1e-5, 1),
                            gn_in=(p1[0], p1[1], self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1) + tuple(p1[2:]))
         else:
             g1 = self.gn(x, skip, self.f(name + ".norm1.weight"), self.f(name + ".norm1.bias"), 1e-5, 1)
             h1 = self.conv(g1, w1, (b, h, w_, cout), bias=self.f(name + ".conv1.bias"),
-                           rowvec=self.temb_rows[:, off:off + cout], gn_stats=True)
+                           rowvec=self.temb_rows[:, off:off + cout], gn_stats=True, fuse_gn=self._gn_of(name + ".norm2", 1e-5, 1))
             self.pool.put(g1)
         if cin != cout:
             res = self.conv(x, self.w(name + ".conv_shortcut.weight"), (b, h, w_, cout), x2=skip,
@@ -563,13 +592,13 @@ class UNetPlan(_Plan):
         w2 = self.w(name + ".conv2.weight")
         p2 = self.gn_in_conv_ok(h1, None, w2, (b, h, w_, cout), res)
         if p2 is not None:           # norm2 + SiLU inside conv2
-            out = self.conv(h1, w2, (b, h, w_, cout), bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True,
+            out = self.conv(h1, w2, (b, h, w_, cout), bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True, fuse_gn=next_gn,
                             gn_in=(p2[0], p2[1], self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1))
             self.pool.put(h1)
         else:
             g2 = self.gn(h1, None, self.f(name + ".norm2.weight"), self.f(name + ".norm2.bias"), 1e-5, 1)
             self.pool.put(h1)
-            out = self.conv(g2, w2, (b, h, w_, cout), bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True)
+            out = self.conv(g2, w2, (b, h, w_, cout), bias=self.f(name + ".conv2.bias"), residual=res, gn_stats=True, fuse_gn=next_gn)
             self.pool.put(g2)
         if res is not x:
             self.pool.put(res)
@@ -745,11 +774,24 @@ class UNetPlan(_Plan):
     def _build(self):
         b, s = self.B, self.S
         h = self.pool.get((b, s, s, 320))
-        self.rec(self.be.conv_in_nchw, self.lat_in, self.w("conv_in.weight", pack_conv_cin8), self.f("conv_in.bias"), h)
+        gkw = {}
+        if GN_FROM_EPILOGUE and (s * s) % 256 == 0 and (s * s) // 256 <= 128 and s * s * 10 * 2 > GN_FUSED_MAX_BYTES:
+            # conv_in writes the GroupNorm chunk partials of its output (256 pixels per chunk): no statistics pass for the
+            # first ResNet's norm1 nor for the last up block's skip-concat, and both can normalise inside their 3x3 conv
+            nchunk = (s * s) // 256
+            ws = self.be.zeros((b * nchunk * GROUPS * 2,), F32)
+            self.keep.append(ws)
+            self.gn_partials[h.data_ptr()] = (ws, nchunk)
+            gkw = dict(gn_ws=ws, gn_nchunk=nchunk)
+        self.rec(self.be.conv_in_nchw, self.lat_in, self.w("conv_in.weight", pack_conv_cin8), self.f("conv_in.bias"), h, **gkw)
         skips = [h]
         for i in range(4):
             for j in range(2):
-                hn = self._resnet(f"down_blocks.{i}.resnets.{j}", h)
+                if i < 3:
+                    nxt = self._gn_of(f"down_blocks.{i}.attentions.{j}.norm", 1e-6, 0)
+                else:
+                    nxt = self._gn_of("down_blocks.3.resnets.1.norm1" if j == 0 else "mid_block.resnets.0.norm1", 1e-5, 1)
+                hn = self._resnet(f"down_blocks.{i}.resnets.{j}", h, next_gn=nxt)
                 if h is not skips[-1]:
                     self.pool.put(h)
                 h = hn
@@ -762,9 +804,10 @@ class UNetPlan(_Plan):
                 c = h.shape[-1]
                 h = self.conv(h, self.w(f"down_blocks.{i}.downsamplers.0.conv.weight"),
                               (b, h.shape[1] // 2, h.shape[2] // 2, c),
-                              bias=self.f(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=1, gn_stats=True)
+                              bias=self.f(f"down_blocks.{i}.downsamplers.0.conv.bias"), stride=2, pad=1, gn_stats=True,
+                              fuse_gn=self._gn_of(f"down_blocks.{i + 1}.resnets.0.norm1", 1e-5, 1))
                 skips.append(h)
-        hn = self._resnet("mid_block.resnets.0", h)        # h is skips[-1]: keep
+        hn = self._resnet("mid_block.resnets.0", h, next_gn=self._gn_of("mid_block.attentions.0.norm", 1e-6, 0))        # h is skips[-1]: keep
         h = hn
         hn = self._transformer("mid_block.attentions.0", h)
         self.pool.put(h)
@@ -773,7 +816,8 @@ class UNetPlan(_Plan):
         for i in range(4):
             for j in range(3):
                 skip = skips.pop()
-                hn = self._resnet(f"up_blocks.{i}.resnets.{j}", h, skip)
+                hn = self._resnet(f"up_blocks.{i}.resnets.{j}", h, skip,
+                                  next_gn=self._gn_of(f"up_blocks.{i}.attentions.{j}.norm", 1e-6, 0) if i > 0 else None)
                 self.pool.put(h, skip)
                 h = hn
                 if i > 0:
@@ -790,6 +834,7 @@ class UNetPlan(_Plan):
         g = self.gn(h, None, self.f("conv_norm_out.weight"), self.f("conv_norm_out.bias"), 1e-5, 1)
         self.rec(self._emit_eps, g, self.w("conv_out.weight", pack_conv_cout4), self.f("conv_out.bias"))
         self.pool.put(h, g)
+        assert not self.gn_ready, "a GroupNorm written by a finish kernel was never consumed"
 
     # -- step-invariant preparation ----------------------------------------------------------------
     def set_cond(self, cond: torch.Tensor, slot: int = 0):

@@ -19,6 +19,7 @@ DADD_OK, DADD_EINVAL, DADD_EHIP, DADD_ESTATE = 0, -1, -2, -3
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
 EPI_LNFOLD, EPI_QUICKGELU, EPI_GELU, EPI_SIGMOID, EPI_GNSTAT, EPI_LNSTAT = 128, 256, 512, 1024, 2048, 4096
 PRE_GN, PRE_GN_SILU = 8192, 16384
+EPI_GNAPPLY, EPI_GNAPPLY_SILU = 32768, 65536
 TUNE_SHALLOW, TUNE_NODMA, TUNE_PERSIST = 16, 32, 64
 XATTN_SPLIT, XATTN_BASELINE = 0, 1
 GN_MAX_CHUNKS = 256
@@ -34,7 +35,8 @@ class IgemmDesc(C.Structure):
                                    "tile_n", "tile_m")] + [("counters", vp), ("ln_c1", vp), ("ln_eps", f32), ("gn_ws", vp), ("gn_nchunk", i32), ("gn_cg", i32),
                                                            ("ln_stats_out", vp), ("ln_stats_in", vp), ("ln_parts_out", i32), ("ln_parts_in", i32),
                                                            ("gn_in_ws", vp), ("gn_in_gamma", vp), ("gn_in_beta", vp), ("gn_in_nchunk", i32), ("gn_in_eps", f32),
-                                                           ("gn_in_ws2", vp), ("gn_in_nchunk2", i32)]
+                                                           ("gn_in_ws2", vp), ("gn_in_nchunk2", i32),
+                                                           ("gn_out", vp), ("gn_out_gamma", vp), ("gn_out_beta", vp), ("gn_out_eps", f32)]
 
 
 # name -> (restype, argtypes); every symbol include/dadd_hip.h declares
@@ -45,7 +47,7 @@ PROTOTYPES = {
     "dadd_device_info": (C.c_int, [C.c_int, C.POINTER(i64)]),
     "dadd_conv_igemm_f16": (C.c_int, [C.POINTER(IgemmDesc), vp]),
     "dadd_conv3x3_cin8_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    "dadd_conv_in_nchw_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dadd_conv_in_nchw_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
     "dadd_conv3x3_cout4_f16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, vp]),
     "dadd_conv_out_ddim_f16": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

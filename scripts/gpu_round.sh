@@ -2,7 +2,7 @@
 # One gpurun call = one box acquisition (minutes of budget): run the whole GPU checklist in it.
 # A step that TIMES OUT or is KILLED ends the call (no further GPU work on a possibly wedged card);
 # ordinary test failures are logged and the later steps still run.
-# usage: scripts/gpu_round.sh <tag> [steps...]   steps: full kernels parity smoke stepprof stepprofvae bench prof pmc
+# usage: scripts/gpu_round.sh <tag> [steps...]   steps: full kernels parity smoke stepprof stepprofvae breakdown bench prof pmc
 set -u
 tag=${1:-r01}; shift || true
 steps=${*:-"kernels parity smoke bench prof"}
@@ -39,6 +39,7 @@ for s in $steps; do
     stepprofvae) TAILN=40 run stepprofvae 600 python scripts/step_profile.py --vae --list --out "$out/step_profile_vae.txt" ;;
     opbench) TAILN=80 run opbench 600 python scripts/op_bench.py "$tag" ;;
     opbenchvae) TAILN=60 run opbenchvae 600 python scripts/op_bench.py "$tag" --vae ;;
+    breakdown) TAILN=20 run breakdown 600 python scripts/pass_breakdown.py ;;
     bench)   run bench 900 python bench.py --steps 3 --warmup 1 ;;
     prof)    export TMPDIR=/tmp
              run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline

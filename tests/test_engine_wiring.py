@@ -97,7 +97,14 @@ def test_unet_plan_matches_oracle(unet_sd, lam, fold, monkeypatch):
     assert (ref - got).abs().max().item() < 6e-3 * max(1.0, ref.abs().max().item())
     # every pooled buffer is handed back exactly once: no leak of plan-time buffers
     n_ln = sum(1 for fn, _, _ in plan.ops if getattr(fn, "__name__", "") == "layernorm")
-    assert n_ln == (len(plan.a2) if fold else 48) and len(plan.ops) > 250     # fused-attn2 sites keep LayerNorm 2
+    assert n_ln == (len(plan.a2) if fold else 48) and len(plan.ops) > 200     # fused-attn2 sites keep LayerNorm 2
+    # on these small maps every conv runs split-K and its finish kernel writes the next GroupNorm (DADD_EPI_GNAPPLY): only
+    # the GroupNorms over a skip-concat, behind a non-split linear (transformer -> ResNet) and conv_norm_out stay launches
+    n_gn = sum(1 for fn, _, _ in plan.ops if getattr(fn, "__name__", "") == "groupnorm")
+    monkeypatch.setattr(E, "FINISH_GN_APPLY", False)
+    n_gn_plain = sum(1 for fn, _, _ in E.UNetPlan(TorchRefBackend(), unet_sd, b, s).ops if getattr(fn, "__name__", "") == "groupnorm")
+    monkeypatch.setattr(E, "FINISH_GN_APPLY", True)
+    assert n_gn_plain == 61 and n_gn <= 30, (n_gn_plain, n_gn)
     monkeypatch.setattr(E, "LN_FOLD", "auto")                  # the shipped policy: fold on 64-row tiles only
     n_auto = sum(1 for fn, _, _ in E.UNetPlan(TorchRefBackend(), unet_sd, b, s).ops if getattr(fn, "__name__", "") == "layernorm")
     assert 0 <= n_auto <= 48
@@ -419,10 +426,10 @@ def test_groupnorm_statistics_from_the_producing_epilogue(monkeypatch):
     assert (y.float() - ref).abs().max().item() < 4e-3
     plan.pool.put(out)                                   # a recycled buffer must not keep its statistics
     assert out.data_ptr() not in plan.gn_partials
-    # split-K: the finish kernel writes the partials (64-row chunks); 64-column tiles: no partials, two-pass GroupNorm
+    # split-K: the finish kernel writes the partials (SPLITK_GN_ROWS-row chunks); 64-column tiles: no partials, two-pass GroupNorm
     monkeypatch.setitem(E.TILING_OVERRIDE, E.tiling_key(b * hw * hw, cout, 9 * cin, 9, False, True), (128, 160, 2, 0))
     out2 = plan.conv(x, w, (b, hw, hw, cout), bias=bias, residual=res, gn_stats=True)
-    assert plan.gn_partials[out2.data_ptr()][1] == hw * hw // 64
+    assert plan.gn_partials[out2.data_ptr()][1] == hw * hw // E.SPLITK_GN_ROWS
     y2 = plan.gn(out2, None, gamma, beta, 1e-5, 1)
     plan.ops[-2][0](*plan.ops[-2][1], **plan.ops[-2][2])
     plan.ops[-1][0](*plan.ops[-1][1], **plan.ops[-1][2])

@@ -697,6 +697,24 @@ def test_thin_convs_and_pack(hip):
         hip.conv_in_nchw(dev(hip, lat2), dev(hip, w), dev(hip, bias), o2)
         hip.synchronize()
         close(o2, o_ref2, 3e-3, 2e-3, "conv_in_nchw")
+    # ... and with the GroupNorm chunk partials of its output (256 pixels per chunk): same pixels bit for bit, the partials
+    # equal to the sums over the kernel's own rounded outputs
+    for bb, ss in ((2, 16), (3, 32)):
+        lat2 = rnd((bb, 4, ss, ss), 45, 1.0, F32)
+        nchunk = ss * ss // 256
+        o_plain, o_gn = hip.zeros((bb, ss, ss, 320), F16), hip.zeros((bb, ss, ss, 320), F16)
+        ws = hip.zeros((bb * nchunk * 64,), F32)
+        hip.conv_in_nchw(dev(hip, lat2), dev(hip, w), dev(hip, bias), o_plain)
+        hip.conv_in_nchw(dev(hip, lat2), dev(hip, w), dev(hip, bias), o_gn, gn_ws=ws, gn_nchunk=nchunk)
+        hip.synchronize()
+        assert torch.equal(o_plain.cpu(), o_gn.cpu())
+        of = o_gn.cpu().double().reshape(bb, nchunk, 256, 32, 10)
+        want = torch.stack([of.sum(dim=(2, 4)), (of * of).sum(dim=(2, 4))], dim=-1)
+        got = ws.cpu().double().reshape(bb, nchunk, 32, 2)
+        assert torch.allclose(got, want, rtol=2e-5, atol=1e-3), float((got - want).abs().max())
+    with pytest.raises(ValueError):      # 21 x 21 pixels: not whole 256-pixel chunks
+        hip.conv_in_nchw(dev(hip, rnd((1, 4, 21, 21), 46, 1.0, F32)), dev(hip, w), dev(hip, bias), hip.zeros((1, 21, 21, 320), F16),
+                         gn_ws=hip.zeros((64,), F32), gn_nchunk=1)
     for c, co, mode in ((320, 4, 0), (128, 3, 1)):
         x = rnd((b, s, s, c), 39, 1.0)
         w = rnd((co, 9, c), 40, 1 / math.sqrt(9 * c) * (4.0 if mode else 1.0))
@@ -880,6 +898,45 @@ def test_conditioning_small_kernels(hip):
     REF.purifier_tail(img, dis, gate, gam, bet, oref)
     hip.synchronize()
     assert (o.cpu() - oref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("case", ["conv8x8", "down8x8", "lin4x4"])
+def test_splitk_finish_with_groupnorm_apply(hip, case):
+    """DADD_EPI_GNAPPLY: on a small map the split-K finish kernel also writes GroupNorm (+ SiLU) of the output.  Same
+    arithmetic in the same order as splitk_finish_kernel followed by the single-launch GroupNorm: both tensors bit-identical
+    to the two-launch path."""
+    from progressive_stable_diffusion_amd import lib as L
+    if case == "conv8x8":       # a ResNet conv of the 8x8 level: bias + time row + residual, SiLU
+        b, hw, cin, n, taps, stride, sk, silu, fl = 4, 8, 1280, 1280, 9, 1, 9, 1, 7
+    elif case == "down8x8":     # the stride-2 downsampler 16x16 -> 8x8: bias only
+        b, hw, cin, n, taps, stride, sk, silu, fl = 2, 8, 640, 640, 9, 2, 5, 1, 1
+    else:                       # a 1x1 linear on a 4x4 map, three slices (tail of the four-in-flight loop), no SiLU
+        b, hw, cin, n, taps, stride, sk, silu, fl = 3, 4, 1280, 2560, 1, 1, 3, 0, 5
+    hi = hw * stride
+    x, w = rnd((b, hi, hi, cin), 120), rnd((n, taps * cin), 121, 1 / math.sqrt(taps * cin))
+    bias, rowvec, res = rnd((n,), 122, 0.1, F32), rnd((b, n), 123, 0.3, F32), rnd((b, hw, hw, n), 124)
+    gamma, beta = rnd((n,), 125, 0.1, F32) + 1.0, rnd((n,), 126, 0.1, F32)
+    kw = dict(bias=dev(hip, bias), taps=taps, stride=stride, pad=taps // 9, tile_m=128, tile_n=160 if n % 160 == 0 else 128, splitk=sk)
+    if fl & 2:
+        kw["rowvec"] = dev(hip, rowvec)
+    if fl & 4:
+        kw["residual"] = dev(hip, res)
+    xd, wd = dev(hip, x), dev(hip, w)
+    o1, o2, y1, y2 = (hip.zeros((b, hw, hw, n), F16) for _ in range(4))
+    hip.igemm(xd, wd, o1, flags=fl, partial=hip.zeros((sk * b * hw * hw * n,), F32), **kw)
+    hip.groupnorm(o1, None, dev(hip, gamma), dev(hip, beta), y1, hip.zeros((b * L.GN_MAX_CHUNKS * 64,), F32), 32, 1e-5, silu)
+    hip.igemm(xd, wd, o2, flags=fl | L.EPI_GNAPPLY | (L.EPI_GNAPPLY_SILU if silu else 0),
+              partial=hip.zeros((sk * b * hw * hw * n,), F32), gn_apply=(y2, dev(hip, gamma), dev(hip, beta), 1e-5), **kw)
+    hip.synchronize()
+    o_ref, y_ref = torch.zeros(b, hw, hw, n, dtype=F16), torch.zeros(b, hw, hw, n, dtype=F16)
+    REF.igemm(x, w, o_ref, flags=fl | (L.EPI_GNAPPLY_SILU if silu else 0), bias=bias, rowvec=rowvec if fl & 2 else None,
+              residual=res if fl & 4 else None, taps=taps, stride=stride, pad=taps // 9, gn_apply=(y_ref, gamma, beta, 1e-5))
+    close(o2, o_ref, 3e-3, 2e-3, f"finish+gn out {case}")
+    close(y2, y_ref, 6e-3, 6e-3, f"finish+gn normalised {case}")
+    assert torch.equal(o1.cpu(), o2.cpu()), case
+    assert torch.equal(y1.cpu(), y2.cpu()), case
+    with pytest.raises(ValueError):        # one K pass: there is no finish kernel to do it
+        hip.igemm(xd, wd, o2, flags=fl | L.EPI_GNAPPLY, gn_apply=(y2, dev(hip, gamma), dev(hip, beta), 1e-5), **{**kw, "splitk": 1})
 
 
 @pytest.mark.parametrize("case", ["halo64", "dma128x160", "dma64x160", "dma128x128", "reg64x160"])

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_GEGLU = 1, 2, 4, 8
+EPI_GNAPPLY_SILU = 65536
 
 
 def geglu_deinterleave_index(n: int) -> torch.Tensor:
@@ -80,10 +81,15 @@ class TorchRefBackend:
         y = F.conv2d(x.float().permute(0, 3, 1, 2), wt, None if bias is None else bias.float(), padding=1)
         out.copy_(y.permute(0, 2, 3, 1).to(out.dtype))
 
-    def conv_in_nchw(self, x, w, bias, out):
+    def conv_in_nchw(self, x, w, bias, out, gn_ws=None, gn_nchunk=0):
         x8 = torch.zeros(x.shape[0], x.shape[2], x.shape[3], 8, dtype=torch.float16)
         self.pack_latents(x, x8)
         self.conv_cin8(x8, w, bias, out)
+        if gn_ws is not None:           # chunk partials of the rounded output, [B][nchunk][32][2]
+            b, h, wd, c = out.shape
+            o = out.float().reshape(b, gn_nchunk, (h * wd) // gn_nchunk, 32, c // 32)
+            st = torch.stack([o.sum(dim=(2, 4)), (o * o).sum(dim=(2, 4))], dim=-1)
+            gn_ws[:b * gn_nchunk * 64].copy_(st.reshape(-1))
 
     def conv_out_ddim(self, x, w, bias, latents, coef):
         eps = torch.empty_like(latents)
@@ -115,7 +121,7 @@ class TorchRefBackend:
 
     def igemm(self, x, w, out, *, x2=None, bias=None, rowvec=None, residual=None, taps=1, stride=1,
               ups=0, pad=0, flags=0, splitk=1, partial=None, tile_n=0, tile_m=0, counters=None, ln_c1=None,
-              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None):
+              ln_eps=1e-5, gn_ws=None, gn_nchunk=0, ln_stats_out=None, ln_stats_in=None, gn_in=None, gn_apply=None):
         self.launches += 1
         if gn_in is not None:           # PRE_GN: GroupNorm (+ SiLU) of x from its chunk partials, rounded to fp16 like gn_apply
             ws_in, nch_in, gam, bet, eps_in = gn_in[:5]
@@ -163,6 +169,7 @@ class TorchRefBackend:
                 var = (xin * xin).mean(dim=-1, keepdim=True) - mu * mu
             y = torch.rsqrt(var.clamp_min(0.0) + ln_eps) * (y - mu * ln_c1.float())
         act = flags & (256 | 512 | 1024)
+        gn_apply_silu = bool(flags & EPI_GNAPPLY_SILU)
         flags &= 15                     # tuning bits (16, 32) do not change the math
         if flags & EPI_BIAS:
             y = y + bias.float()
@@ -188,6 +195,9 @@ class TorchRefBackend:
             o = out.float().reshape(b, gn_nchunk, -1, 32, n // 32)
             part = torch.stack([o.sum(dim=(2, 4)), (o * o).sum(dim=(2, 4))], dim=-1)
             gn_ws[: part.numel()].copy_(part.reshape(-1))
+        if gn_apply is not None:        # EPI_GNAPPLY: GroupNorm (+ SiLU) of the rounded output, written beside it
+            g_out, gam, bet, eps_o = gn_apply
+            self.groupnorm(out, None, gam, bet, g_out, None, 32, eps_o, gn_apply_silu)
 
     def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu, ws_chunks=0):
         x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
