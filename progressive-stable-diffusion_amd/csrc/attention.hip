@@ -66,7 +66,26 @@ struct FlashArgs {
   half_t* out;
   int B, Nq, N, H, ldq, ld, ldo;   // Nq query rows (ldq), N key / value rows (ld) per sample
   float scale_log2;  // log2(e)/sqrt(d)
+#ifdef DADD_FLASH_STAMPS
+  unsigned long long* dbg;   // diagnostics build only (scripts/flash_stamps.py): per (block, wave) sums of phase cycles
+#endif
 };
+
+// Diagnostics build (-DDADD_FLASH_STAMPS, never the shipped library): s_memtime between the phases of a tile, pinned with
+// scheduling barriers (which also forbid the interleaving the product build relies on: the sums tell where a wave waits, not
+// what the product kernel costs).
+#ifdef DADD_FLASH_STAMPS
+#define FSTAMP(i)                                                    \
+  {                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    stamp_acc[i] += now_ - stamp_last;                               \
+    stamp_last = now_;                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  }
+#else
+#define FSTAMP(i)
+#endif
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
@@ -102,15 +121,16 @@ __device__ __forceinline__ int kpanel_off(int row, int chunk) {
 // 512 (the other 256 are AGPRs, reachable by VALU only through v_accvgpr moves): hipcc emitted 1,160 of those moves per
 // iteration pair and the kernel took 327 us against 171 (same box, profiles/r03_o_flash_pipe_ab.txt).  Not kept; what
 // the counters say about this kernel is in profiles/r03_n_pmc_flash.txt: VALU issuing 50 % of the time, MFMA pipe 30 %.)
-template <int DR, int QF, bool PREFETCH>
-__global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const FlashArgs p) {
+template <int DR, int QF, bool PREFETCH, int NW = 4>
+__global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const FlashArgs p) {
+  constexpr int NT = NW * 64, QB = NW * 16 * QF;   // threads, queries per block
   constexpr bool DEEP = PREFETCH && DR <= 40;   // two tiles in flight where the registers allow it
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int KS = D / 32, DF = DVP / 16, DC = DR / 8;
   constexpr int KP = (D + 63) / 64, KTILE = KP * 64 * 64;       // halfs
   constexpr int VLD = v_stride(DVP), VTILE = 64 * VLD;
   constexpr int TILE_HALFS = KTILE + VTILE;
-  constexpr int NL = (64 * DC + 255) / 256;  // 16-byte loads per thread per tile per tensor
+  constexpr int NL = (64 * DC + NT - 1) / NT;  // 16-byte loads per thread per tile per tensor
   constexpr bool SUMCOL = DVP > DR;          // spare V column available for the row sums
   constexpr int NBUFS = PREFETCH ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,19 +140,19 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4, li = lane & 15;
   // 1-D grid, XCD-aware: the query blocks of one (batch, head) run on ONE XCD, so its K/V (0.6-1.3 MB)
   // is fetched into one L2 instead of all eight (FETCH_SIZE 170 MB -> ~1/5 for 4x4096x8x40)
-  const int nqb = (p.Nq + 64 * QF - 1) / (64 * QF);
+  const int nqb = (p.Nq + QB - 1) / QB;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = tile / nqb, qb = tile - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int qw0 = qb * (64 * QF) + wave * (16 * QF);
+  const int qw0 = qb * QB + wave * (16 * QF);
   const size_t tok0 = (size_t)b * p.N, qtok0 = (size_t)b * p.Nq;
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // zero both buffers once (padding columns are never written again); ones column for the row sums
-  for (int i = t; i < NBUFS * TILE_HALFS / 8; i += 256) *reinterpret_cast<h8*>(Ks + i * 8) = zero8;
+  for (int i = t; i < NBUFS * TILE_HALFS / 8; i += NT) *reinterpret_cast<h8*>(Ks + i * 8) = zero8;
   __syncthreads();
   if (SUMCOL)
-    for (int i = t; i < NBUFS * 64; i += 256) Vs[(i >> 6) * TILE_HALFS + (i & 63) * VLD + DR] = (half_t)1.0f;
+    for (int i = t; i < NBUFS * 64; i += NT) Vs[(i >> 6) * TILE_HALFS + (i & 63) * VLD + DR] = (half_t)1.0f;
 
   // Q fragments (B operand of S^T = K Q^T): lane -> query li, d-chunk 32s + 8g
   h8 qf[QF][KS];
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
   int g_off[SLIM ? 1 : NL], g_off_c[NL], k_lds[NL], v_lds[NL], t_row[NL];
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
-    const int idx = t + 256 * u;
+    const int idx = t + NT * u;
     const int row = idx / DC, ch = idx - row * DC;
     t_row[u] = (idx < 64 * DC) ? row : 1 << 30;      // rows past the tile never pass the key test
     // in-tile address for every thread: a thread without a row (row >= 64) gets a clamped address and never stores; for
@@ -228,6 +248,9 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
   };
 
   const bool ragged = (p.N & 63) != 0;
+#ifdef DADD_FLASH_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   auto compute = [&](int kt, int buf) {
     const half_t* Kc = Ks + buf * TILE_HALFS;
     const half_t* Vc = Vs + buf * TILE_HALFS;
@@ -248,6 +271,7 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
       }
     }
 
+    FSTAMP(2)   // K fragment reads + S MFMAs issued
     // ---- online softmax per query column
     h8 pb[QF][2];
     if (ragged && kt == nkt - 1) {
@@ -260,49 +284,67 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
           for (int r = 0; r < 4; ++r)
             if (kbase_i + kf * 16 + r >= p.N) sacc[kf][f][r] = -3.0e38f;
     }
+    // One basic block for the whole tile (measured with the DADD_FLASH_STAMPS build, profiles/r03_w_flash_stamps.txt: the
+    // per-fragment "did a maximum move" branches and the eight-deep maximum chains left a wave 2,280 ticks in this phase for
+    // ~250 vector instructions).  Now: the 16 scores of a query column reduce in a depth-3 tree of three-input maxima, the QF
+    // fragments are independent instruction streams for the scheduler, and the running maximum is only RAISED when a column's
+    // new maximum exceeds it by more than 2^8 (the probabilities then stay <= 256: exact in fp16 / fp32 sums, the final
+    // division by the row sum cancels the stale scale) - after the first tiles the wave-uniform rescale branch is rarely taken.
+    float mc[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
-      // 16 scores -> one maximum in 8 three-input maxima (v_max3_f32), a linear chain the compiler keeps as such
-      float mx = vmax2(sacc[0][f][0], sacc[0][f][1]);
-      mx = vmax3(mx, sacc[0][f][2], sacc[0][f][3]);
+      const float t0 = vmax3(sacc[0][f][0], sacc[0][f][1], sacc[0][f][2]);
+      const float t1 = vmax3(sacc[0][f][3], sacc[1][f][0], sacc[1][f][1]);
+      const float t2 = vmax3(sacc[1][f][2], sacc[1][f][3], sacc[2][f][0]);
+      const float t3 = vmax3(sacc[2][f][1], sacc[2][f][2], sacc[2][f][3]);
+      const float t4 = vmax3(sacc[3][f][0], sacc[3][f][1], sacc[3][f][2]);
+      mc[f] = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, sacc[3][f][3]));
+    }
 #pragma unroll
-      for (int kf = 1; kf < 4; ++kf) {
-        mx = vmax3(mx, sacc[kf][f][0], sacc[kf][f][1]);
-        mx = vmax3(mx, sacc[kf][f][2], sacc[kf][f][3]);
+    for (int f = 0; f < QF; ++f) {   // the maximum over the four lanes that share a query column: permlane swaps (VALU)
+      float ua, ub;
+      dadd_pair16(mc[f], ua, ub);
+      mc[f] = vmax2(ua, ub);
+    }
+    bool need = false;
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      float ua, ub;
+      dadd_pair32(mc[f], ua, ub);
+      mc[f] = vmax2(ua, ub) * p.scale_log2;                      // log2 units
+      need = need || (mc[f] > mrow[f] + 8.0f);
+    }
+    if (__any(need)) {                                             // wave-uniform branch
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        const float mnew = (mc[f] > mrow[f] + 8.0f) ? mc[f] : mrow[f];
+        const float alpha = __builtin_amdgcn_exp2f(mrow[f] - mnew);   // 1 where the column keeps its maximum
+        mrow[f] = mnew;
+        if (!SUMCOL) lrow[f] *= alpha;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
       }
-      {   // the maximum over the four lanes that share a query column: permlane swaps (VALU), not ds_bpermute + wait
-        float ua, ub;
-        dadd_pair16(mx, ua, ub);
-        mx = vmax2(ua, ub);
-        dadd_pair32(mx, ua, ub);
-        mx = vmax2(ua, ub);
-      }
-      const float mnew = vmax2(mrow[f], mx * p.scale_log2);      // running max in log2 units
-      const bool moved = mnew > mrow[f];
+    }
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
       float rs = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][r], p.scale_log2, -mnew));
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][r], p.scale_log2, -mrow[f]));
           sacc[kf][f][r] = pv;
           if (!SUMCOL) rs += pv;
         }
-      if (__any(moved)) {                                        // wave-uniform branch
-        const float alpha = __builtin_amdgcn_exp2f(mrow[f] - mnew);
-        if (!SUMCOL) lrow[f] *= alpha;
-#pragma unroll
-        for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
-      }
       if (!SUMCOL) {
         rs = dadd_sum_x16x32(rs);
         lrow[f] += rs;
       }
-      mrow[f] = mnew;
       pb[f][0] = pack_p8(sacc[0][f], sacc[1][f]);
       pb[f][1] = pack_p8(sacc[2][f], sacc[3][f]);
     }
 
+    FSTAMP(3)   // softmax (waits for the S MFMAs)
     // ---- O^T += V^T P^T   (with SUMCOL, row DR of O^T accumulates sum_k P = the softmax denominator)
 #pragma unroll
     for (int df = 0; df < DF; ++df) {
@@ -315,6 +357,7 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
           oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[f][kb], oacc[df][f], 0, 0, 0);
       }
     }
+    FSTAMP(4)   // V fragment reads + PV MFMAs issued
   };
 
   if (DEEP) {
@@ -328,16 +371,28 @@ __global__ __launch_bounds__(256, DR <= 96 ? 2 : 1) void flash_kernel(const Flas
     int kt = 0;
     while (kt < nkt) {
       __syncthreads();   // tile kt visible in buffer 0; everyone finished reading tile kt-1 (buffer 1)
+      FSTAMP(0)   // barrier
       if (kt + 2 < nkt) tile_load(kt + 2, rk0, rv0);
+      FSTAMP(1)   // global loads issued
       compute(kt, 0);
       if (kt + 1 < nkt) tile_store(1, rk1, rv1);
+      FSTAMP(5)   // LDS stores of the next tile (wait for its global loads)
       if (++kt >= nkt) break;
       __syncthreads();
+      FSTAMP(0)
       if (kt + 2 < nkt) tile_load(kt + 2, rk1, rv1);
+      FSTAMP(1)
       compute(kt, 1);
       if (kt + 1 < nkt) tile_store(0, rk0, rv0);
+      FSTAMP(5)
       ++kt;
     }
+#ifdef DADD_FLASH_STAMPS
+    if (p.dbg != nullptr && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p.dbg[((size_t)blockIdx.x * NW + wave) * 8 + i] = stamp_acc[i];
+    }
+#endif
   } else if (PREFETCH) {
     tile_load(0, rk0, rv0);
     __syncthreads();
@@ -543,23 +598,25 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
   }
 }
 
-template <int DR, int QF, bool PF>
+template <int DR, int QF, bool PF, int NW = 4>
 int flash_attr() {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int smem = (PF ? 2 : 1) * (((D + 63) / 64) * 4096 + 64 * v_stride(DVP)) * (int)sizeof(half_t);
-  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<DR, QF, PF>),
+  DADD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_kernel<DR, QF, PF, NW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   return DADD_OK;
 }
 
-template <int DR, int QF, bool PF>
+template <int DR, int QF, bool PF, int NW = 4>
 int launch_flash(const FlashArgs& a, hipStream_t s) {
   constexpr int D = round_up(DR, 32), DVP = round_up(DR, 16);
   constexpr int smem = (PF ? 2 : 1) * (((D + 63) / 64) * 4096 + 64 * v_stride(DVP)) * (int)sizeof(half_t);
-  dim3 grid(((a.Nq + 64 * QF - 1) / (64 * QF)) * a.B * a.H);
-  static const std::string name = "flash_kernel<" + std::to_string(DR) + ", " + std::to_string(QF) + ", " + (PF ? "true" : "false") + ">";
+  constexpr int QB = NW * 16 * QF;
+  dim3 grid(((a.Nq + QB - 1) / QB) * a.B * a.H);
+  static const std::string name = "flash_kernel<" + std::to_string(DR) + ", " + std::to_string(QF) + ", " + (PF ? "true" : "false") +
+                                  (NW == 4 ? "" : ", " + std::to_string(NW)) + ">";
   const double tok = (double)a.B * a.Nq, c = (double)a.H * DR;
-  dadd_launch({name.c_str(), 4.0 * tok * a.N * c, (tok + (double)a.B * a.N) * c * 2.0 * 2.0}, flash_kernel<DR, QF, PF>, grid, dim3(256), smem, s, a);
+  dadd_launch({name.c_str(), 4.0 * tok * a.N * c, (tok + (double)a.B * a.N) * c * 2.0 * 2.0}, flash_kernel<DR, QF, PF, NW>, grid, dim3(NW * 64), smem, s, a);
   DADD_LAUNCH_CHECK();
   return DADD_OK;
 }
@@ -586,6 +643,7 @@ int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
 int dadd_init_attention() {
   int rc = flash_attr<40, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<40, 4, true>();
+  if (rc == DADD_OK) rc = flash_attr<40, 2, true, 8>();
   if (rc == DADD_OK) rc = flash_attr<64, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<96, 1, true>();
   if (rc == DADD_OK) rc = flash_attr<80, 2, true>();
@@ -593,6 +651,14 @@ int dadd_init_attention() {
   if (rc == DADD_OK) rc = flash_attr<512, 1, false>();
   return rc;
 }
+
+#ifdef DADD_FLASH_STAMPS
+static unsigned long long* g_flash_dbg = nullptr;
+extern "C" int dadd_attn_debug(void* buf) {     // diagnostics build only: 8 x u64 per (block, wave) of the next d = 40 launches
+  g_flash_dbg = static_cast<unsigned long long*>(buf);
+  return DADD_OK;
+}
+#endif
 
 extern "C" int dadd_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int Nq, int Nk,
                              int heads, int d, int ld_q, int ld_kv, int ld_out, void* stream) {
@@ -609,11 +675,18 @@ extern "C" int dadd_attn_f16(const void* q, const void* k, const void* v, void* 
   a.out = static_cast<half_t*>(out);
   a.B = B; a.Nq = Nq; a.N = Nk; a.H = heads; a.ldq = ld_q; a.ld = ld_kv; a.ldo = ld_out;
   a.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+#ifdef DADD_FLASH_STAMPS
+  a.dbg = g_flash_dbg;
+#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d) {
-    case 40:   // 64 queries per wave once the grid still fills the chip (>= 2 blocks per CU)
-      return ((long)B * heads * ((Nq + 255) / 256) >= 512)
-                 ? launch_flash<40, 4, true>(a, s) : launch_flash<40, 2, true>(a, s);
+    case 40: {  // 256 queries per block once the grid still fills the chip (>= 2 blocks per CU): eight waves x 32 queries
+      // (four waves per SIMD, 124 VGPRs) - 149 us against 158 for four waves x 64 queries at 4 x 4096 x 8 heads
+      // (profiles/r03_x_flash_bench.txt; DADD_FLASH40=0 selects the latter for A/B runs)
+      static const int var = getenv("DADD_FLASH40") ? atoi(getenv("DADD_FLASH40")) : 1;
+      if ((long)B * heads * ((Nq + 255) / 256) >= 512) return var == 1 ? launch_flash<40, 2, true, 8>(a, s) : launch_flash<40, 4, true>(a, s);
+      return launch_flash<40, 2, true>(a, s);
+    }
     case 64: return launch_flash<64, 2, true>(a, s);     // CLIP ViT towers (257 tokens, 16 x 64)
     case 80: return launch_flash<80, 2, true>(a, s);
     case 96: return launch_flash<96, 1, true>(a, s);     // nn.MultiheadAttention(768, 8) of the resampler / purifier

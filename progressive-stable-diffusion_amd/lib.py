@@ -103,7 +103,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  With the default AGPR form the
     # attention softmax paid 144 v_accvgpr_read/write per 64-key tile (more than half of its VALU).
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-           "-amdgpu-mfma-vgpr-form=1", *srcs, "-o", LIB_PATH]
+           "-amdgpu-mfma-vgpr-form=1", *os.environ.get("DADD_EXTRA_CFLAGS", "").split(), *srcs, "-o", LIB_PATH]   # (extra flags: diagnostics builds)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
