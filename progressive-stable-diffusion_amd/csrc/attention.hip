@@ -165,14 +165,22 @@ __global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const 
     for (int s = 0; s < KS; ++s) {
       const int dc = 32 * s + 8 * g;
       qf[f][s] = (dc < DR) ? *reinterpret_cast<const h8*>(qp + dc) : zero8;
+      // the softmax scale (in log2 units) rides on Q: the accumulator then holds the exponent itself (see compute())
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[f][s][e] = (half_t)((float)qf[f][s][e] * p.scale_log2);
     }
   }
 
   f4 oacc[DF][QF];
-  float mrow[QF], lrow[QF];
+  // negm[f] = -(reference maximum of query column li of fragment f, log2 units), four copies: it is the C operand of the
+  // first S MFMA of a tile, so the accumulator comes out as  s*scale - m  and goes into v_exp_f32 as it is (MFMA and
+  // vector instructions do not overlap on this SIMD - profiles/r03_y_mfma_valu_coissue.txt - so the fma per score that
+  // this saves is time saved: 64 of ~250 vector instructions per tile)
+  f4 negm[QF];
+  float lrow[QF];
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
-    mrow[f] = -1e30f;
+    negm[f] = f4{0.f, 0.f, 0.f, 0.f};
     lrow[f] = 0.f;
 #pragma unroll
     for (int df = 0; df < DF; ++df) oacc[df][f] = f4{0.f, 0.f, 0.f, 0.f};
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const 
         const h8 ka = *reinterpret_cast<const h8*>(kp + kf * 1024);
 #pragma unroll
         for (int f = 0; f < QF; ++f)
-          sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], s == 0 ? zero4 : sacc[kf][f], 0, 0, 0);
+          sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[f][s], s == 0 ? negm[f] : sacc[kf][f], 0, 0, 0);
       }
     }
 
@@ -286,10 +294,10 @@ __global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const 
     }
     // One basic block for the whole tile (measured with the DADD_FLASH_STAMPS build, profiles/r03_w_flash_stamps.txt: the
     // per-fragment "did a maximum move" branches and the eight-deep maximum chains left a wave 2,280 ticks in this phase for
-    // ~250 vector instructions).  Now: the 16 scores of a query column reduce in a depth-3 tree of three-input maxima, the QF
-    // fragments are independent instruction streams for the scheduler, and the running maximum is only RAISED when a column's
-    // new maximum exceeds it by more than 2^8 (the probabilities then stay <= 256: exact in fp16 / fp32 sums, the final
-    // division by the row sum cancels the stale scale) - after the first tiles the wave-uniform rescale branch is rarely taken.
+    // ~250 vector instructions).  Now: the 16 exponents of a query column reduce in a depth-3 tree of three-input maxima, the
+    // QF fragments are independent instruction streams for the scheduler, and the reference maximum is only MOVED when a
+    // column's exponents exceed 8 (the probabilities then stay <= 256: exact in fp16 / fp32 sums, the final division by the row
+    // sum cancels the stale reference) or in the first tile - after it the wave-uniform re-centring branch is rarely taken.
     float mc[QF];
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -306,23 +314,25 @@ __global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const 
       dadd_pair16(mc[f], ua, ub);
       mc[f] = vmax2(ua, ub);
     }
-    bool need = false;
+    bool need = kt == 0;
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
       float ua, ub;
       dadd_pair32(mc[f], ua, ub);
-      mc[f] = vmax2(ua, ub) * p.scale_log2;                      // log2 units
-      need = need || (mc[f] > mrow[f] + 8.0f);
+      mc[f] = vmax2(ua, ub);
+      need = need || (mc[f] > 8.0f);
     }
     if (__any(need)) {                                             // wave-uniform branch
 #pragma unroll
       for (int f = 0; f < QF; ++f) {
-        const float mnew = (mc[f] > mrow[f] + 8.0f) ? mc[f] : mrow[f];
-        const float alpha = __builtin_amdgcn_exp2f(mrow[f] - mnew);   // 1 where the column keeps its maximum
-        mrow[f] = mnew;
+        const float dlt = (kt == 0 || mc[f] > 8.0f) ? mc[f] : 0.f;    // this column's reference moves by dlt (0: it stays)
+        const float alpha = __builtin_amdgcn_exp2f(-dlt);
+        negm[f] -= dlt;
         if (!SUMCOL) lrow[f] *= alpha;
 #pragma unroll
         for (int df = 0; df < DF; ++df) oacc[df][f] *= alpha;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) sacc[kf][f] -= dlt;
       }
     }
 #pragma unroll
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const 
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][r], p.scale_log2, -mrow[f]));
+          const float pv = __builtin_amdgcn_exp2f(sacc[kf][f][r]);
           sacc[kf][f][r] = pv;
           if (!SUMCOL) rs += pv;
         }
