@@ -155,8 +155,15 @@ def live_roofline(mod, a, side, lat, dev, n_steps=2):
     try:    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tj = json.load(f)
-        if tj.get("dominant", {}).get("kernel", "").replace(" ", "") == dom["name"].replace(" ", ""):
-            traffic, traffic_src = tj["dominant"]["traffic_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc)"
+        want = dom["name"].replace(" ", "")
+        table = dict(tj.get("per_kernel", {}))
+        if "dominant" in tj:
+            table.setdefault(tj["dominant"]["kernel"], tj["dominant"])
+        # exact kernel name first (counter files and launch tags print template arguments alike), then the bare name
+        hit = [v for k, v in table.items() if k.replace(" ", "") == want] or \
+              [v for k, v in table.items() if k.split("<")[0] == dom["name"].split("<")[0] and "<" not in dom["name"]]
+        if hit:
+            traffic, traffic_src = hit[0]["traffic_bytes_per_launch"], "profiles/traffic_latest.json (rocprofv3 --pmc, scripts/pmc_traffic.sh)"
     except (OSError, KeyError, ValueError):
         pass
     gemm = [t for t in rows if t["tflops"] is not None]

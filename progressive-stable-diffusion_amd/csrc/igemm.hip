@@ -416,6 +416,8 @@ __global__ __launch_bounds__(512) void splitk_finish_gnapply_kernel(const IgemmA
   }
 }
 
+constexpr double L2_KEEP = 3.0e6;   // bytes of one operand an XCD's 4 MB L2 can be trusted to keep while the other streams
+
 template <int BM, int BN, bool DEEP>
 int set_attr() {
   constexpr int smem = 2 * (BM + BN) * BK * (int)sizeof(half_t) + (BM == 128 ? (BN == 160 ? 8192 : LN_LDS_BYTES) : 4096);
@@ -559,6 +561,19 @@ extern "C" int dadd_conv_igemm_f16(const dadd_igemm_desc* d, void* stream) {
     } else {
       a.gm = a.mtiles;
       a.gn = (a.ntiles + 7) / 8;
+    }
+    // Linears whose A does not fit one XCD's L2 although W is the larger operand (the GEGLU projection at 32x32: A 5.2 MB,
+    // W 6.5 MB): with "all row tiles x 1/8 of the column tiles" per XCD every XCD streamed all of A once per column tile
+    // (FETCH_SIZE 242 MB for 12 MB of operands).  2-D groups - 1/2 (1/4) of the row tiles x 1/4 (1/2) of the
+    // column tiles per XCD, row tile fastest - keep the XCD's A block (<= L2_KEEP) resident while its weight tiles stream.
+    if (a.taps == 1 && !(a_bytes >= w_bytes) && a_bytes > L2_KEEP) {
+      double best = 1e30;
+      for (int ms = 2; ms <= 4; ms *= 2) {
+        const int ns = 8 / ms;
+        if (a.mtiles % ms || a.ntiles % ns || a_bytes / ms > L2_KEEP) continue;
+        const double fetch = a_bytes / ms + w_bytes / ns;
+        if (fetch < best) { best = fetch; a.gm = a.mtiles / ms; a.gn = a.ntiles / ns; }
+      }
     }
   }
   // K order of the LDS-DMA kernel: channels fastest.  (Taps fastest — the nine taps of a 64-channel chunk as

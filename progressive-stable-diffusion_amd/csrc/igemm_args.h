@@ -69,11 +69,18 @@ __device__ __forceinline__ void tile_decode(const IgemmArgs& p, int tile_id, int
     const int gsz = min(p.gm, p.mtiles - base);
     mt = base + idx % gsz;
     nt = idx / gsz;
-  } else {                                // groups of all row tiles x gn column tiles
+  } else if (p.gm >= p.mtiles) {          // groups of all row tiles x gn column tiles
     const int per = p.mtiles * p.gn;
     const int g = tile_id / per, idx = tile_id - g * per;
     mt = idx % p.mtiles;
     nt = g * p.gn + idx / p.mtiles;
+  } else {                                // 2-D groups of gm x gn tiles (the host guarantees gm | mtiles and gn | ntiles): an XCD
+    const int per = p.gm * p.gn;          // owns a block of A rows that STAYS in its L2 while the block's weight tiles stream by
+    const int g = tile_id / per, idx = tile_id - g * per;
+    const int ngn = p.ntiles / p.gn;
+    const int gmi = g / ngn, gni = g - gmi * ngn;
+    mt = gmi * p.gm + idx % p.gm;
+    nt = gni * p.gn + idx / p.gm;
   }
 }
 

@@ -279,12 +279,13 @@ def test_igemm_kernel_variants(hip, tile_m, tune, splitk, shape):
     close(o, o_ref, 3e-3, 2e-3, f"{shape} tm{tile_m} tune{tune} sk{splitk}")
 
 
-@pytest.mark.parametrize("case", ["qkv", "k1", "k2_ragged", "conv", "geglu", "uneven"])
+@pytest.mark.parametrize("case", ["qkv", "k1", "k2_ragged", "conv", "geglu", "geglu_2d", "uneven"])
 def test_igemm_persistent_ring(hip, case):
     """More 128-row output tiles than CUs and no split-K: on request (DADD_TUNE_PERSIST) the LDS-DMA kernel
     runs its ring as one stream over a contiguous range of output tiles per workgroup.  Cases: K of
     5 / 1 / 2 tiles (the DMA cursor is up to three OUTPUT tiles ahead of the MFMAs), ragged M and N,
-    a 3x3 gather, the GEGLU epilogue, and a tile count that does not divide by the workgroup count."""
+    a 3x3 gather, the GEGLU epilogue (also at the 32x32 level's shape, whose 5.2 MB of A under 6.5 MB of W select the 2-D
+    XCD tile groups of tile_decode), and a tile count that does not divide by the workgroup count."""
     from progressive_stable_diffusion_amd.engine import geglu_interleave
     kw, flags, tile_n = {}, 1, 0
     if case == "qkv":
@@ -299,17 +300,20 @@ def test_igemm_persistent_ring(hip, case):
     elif case == "geglu":
         b, h, c, n = 4, 64, 320, 2560                   # 128 x 20 tiles of 128 x 128
         flags, tile_n = 1 | 8, 128
+    elif case == "geglu_2d":
+        b, h, c, n = 4, 32, 640, 5120                   # 32 x 40 tiles: groups of 16 x 10 per XCD
+        flags, tile_n = 1 | 8, 128
     else:
         b, h, c, n = 1, 200, 192, 480                   # 313 x 3 = 939 tiles over 256 workgroups
     k = c * kw.get("taps", 1)
     x = rnd((b, h, h, c), 70)
-    if case == "geglu":
+    if case.startswith("geglu"):
         w32, b32 = rnd((n, k), 71, 1 / math.sqrt(k), F32), rnd((n,), 72, 0.1, F32)
         w32, bias = geglu_interleave(w32, b32)
         w = w32.to(F16)
     else:
         w, bias = rnd((n, k), 71, 1 / math.sqrt(k)), rnd((n,), 72, 0.1, F32)
-    n_out = n // 2 if case == "geglu" else n
+    n_out = n // 2 if case.startswith("geglu") else n
     res = None
     if case in ("qkv", "conv", "uneven"):
         res, flags = rnd((b, h, h, n), 73), flags | 4
