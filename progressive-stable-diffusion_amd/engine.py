@@ -525,10 +525,39 @@ class UNetPlan(_Plan):
                         fold=False, ln_c1=be.zeros((batch, 384), F32), ln_d=be.zeros((batch, 384), F32),
                         gamma=self.dev(sd[f"{u}{site}.transformer_blocks.0.norm2.weight"].float()),
                         beta=self.dev(sd[f"{u}{site}.transformer_blocks.0.norm2.bias"].float()))
+        # The fold runs once per conditioning (every sampler pass): sites of equal width share ONE set of batched torch
+        # ops over stacked weights / buffers (five sites at 64x64: ~25 launches instead of ~125, profiles/r03_*_pass_breakdown)
+        self.a2_groups = []
+        by_c: Dict[int, List[str]] = {}
+        for site, c in self.sites:
+            if site in self.a2:
+                by_c.setdefault(c, []).append(site)
+        for c, names in by_c.items():
+            self.a2_groups.append(self._a2_group(c, names, batch))
         # ---- I/O
         self.lat_in = be.zeros((batch, 4, side, side), F32)
         self.eps_out = [be.zeros((batch, 4, side, side), F32) for _ in range(2)]
         self._build()
+
+    def _a2_group(self, c, names, batch):
+        """Stacked weights and output buffers of the fused-attn2 sites of width ``c`` (``prepare_attn2``)."""
+        be = self.be
+        ns, d = len(names), c // HEADS
+        with be.ctx():                      # (the stacking reads tensors uploaded on the backend's stream)
+            grp = dict(sites=names, c=c,
+                       wq=torch.stack([self.a2[n]["wq"].view(HEADS, d, c) for n in names]),
+                       wo=torch.stack([self.a2[n]["wo"].view(c, HEADS, d) for n in names]),
+                       gamma=torch.stack([self.a2[n]["gamma"] for n in names]).view(ns, 1, 1, c),
+                       beta=torch.stack([self.a2[n]["beta"] for n in names]).view(ns, 1, 1, c),
+                       gates=torch.stack([self.gates[n] for n in names]).float(),
+                       mcat=be.zeros((ns, batch, 384, c), F16), vw=be.zeros((ns, batch, c, 384), F16),
+                       ln_c1=be.zeros((ns, batch, 384), F32), ln_d=be.zeros((ns, batch, 384), F32))
+        for i, n in enumerate(names):       # the per-site tensors the kernels read are slices of the stacked ones
+            for key in ("mcat", "vw", "ln_c1", "ln_d"):
+                self.a2[n][key] = grp[key][i]
+            del self.a2[n]["wq"], self.a2[n]["wo"]
+        self.keep += [grp[k] for k in ("wq", "wo", "gamma", "beta", "gates", "mcat", "vw", "ln_c1", "ln_d")]
+        return grp
 
     # -- inventory -------------------------------------------------------------------------------
     @staticmethod
@@ -859,33 +888,32 @@ class UNetPlan(_Plan):
             return
         B = self.B
         with self.be.ctx(), torch.no_grad():
-            for site, c in self.sites:
-                st = self.a2.get(site)
-                if st is None:
-                    continue
-                d = c // HEADS
-                kv = self.kv[site][0].view(B, self.T, 4 * c).float()
-                hd = lambda t: t.reshape(B, 16, HEADS, d)                     # noqa: E731
-                ks = [hd(kv[:, 16:32, 0:c]), hd(kv[:, 0:16, 2 * c:3 * c]), hd(kv[:, 32:48, 2 * c:3 * c])]
-                vs = [hd(kv[:, 16:32, c:2 * c]), hd(kv[:, 0:16, 3 * c:4 * c]), hd(kv[:, 32:48, 3 * c:4 * c])]
-                g = self.gates[site]
-                gp = [g[0], g[1], torch.full((), float(lam), device=g.device)]      # (a fill, not an upload: no host wait)
-                wq = st["wq"].view(HEADS, d, c)
-                wo = st["wo"].view(c, HEADS, d)
+            for grp in self.a2_groups:
+                names, c = grp["sites"], grp["c"]
+                ns, d = len(names), c // HEADS
+                kv = torch.stack([self.kv[n][0].view(B, self.T, 4 * c) for n in names]).float()     # s b t 4c
+                hd = lambda t: t.reshape(ns, B, 16, HEADS, d)                     # noqa: E731
+                ks = [hd(kv[:, :, 16:32, 0:c]), hd(kv[:, :, 0:16, 2 * c:3 * c]), hd(kv[:, :, 32:48, 2 * c:3 * c])]
+                vs = [hd(kv[:, :, 16:32, c:2 * c]), hd(kv[:, :, 0:16, 3 * c:4 * c]), hd(kv[:, :, 32:48, 3 * c:4 * c])]
+                g = grp["gates"]                                                  # [s][anat, dis]
+                gp = [g[:, 0].view(ns, 1, 1, 1, 1), g[:, 1].view(ns, 1, 1, 1, 1),
+                      torch.full((), float(lam), device=g.device)]                # (a fill, not an upload: no host wait)
                 scale = math.log2(math.e) / math.sqrt(d)
-                m = torch.stack([torch.einsum("bthd,hdc->bhtc", k, wq) for k in ks], dim=2) * scale   # b h p t c
-                v = torch.stack([torch.einsum("nhd,bthd->bnht", wo, x) * gg for x, gg in zip(vs, gp)], dim=3)  # b n h p t
+                m = torch.stack([torch.einsum("sbthd,shdc->sbhtc", k, grp["wq"]) for k in ks], dim=3) * scale   # s b h p t c
+                v = torch.stack([torch.einsum("snhd,sbthd->sbnht", grp["wo"], x) * gg for x, gg in zip(vs, gp)], dim=4)  # s b n h p t
                 if float(lam) == 0.0:      # routing_gates.py:160,177-178: the delta pathway is skipped, not scaled —
-                    m[:, :, 2] = 0.0       # zero scores and zero values: garbage (NaN) delta tokens cannot leak
-                    v[:, :, :, 2] = 0.0
-                m = m.reshape(B, 384, c)
-                if st["fold"]:             # LayerNorm 2 folded in: S = rstd (x (gamma o M)^T - mu c1) + M beta
-                    st["ln_d"].copy_((m * st["beta"]).sum(dim=-1))
-                    m = m * st["gamma"]
-                st["mcat"].copy_(m)
-                if st["fold"]:             # c1 sums the ROUNDED rows, so that the mean term cancels exactly
-                    st["ln_c1"].copy_(st["mcat"].float().sum(dim=-1))
-                st["vw"].copy_(v.reshape(B, c, 384))
+                    m[:, :, :, 2] = 0.0    # zero scores and zero values: garbage (NaN) delta tokens cannot leak
+                    v[:, :, :, :, 2] = 0.0
+                m = m.reshape(ns, B, 384, c)
+                folds = [bool(self.a2[n]["fold"]) for n in names]
+                if any(folds):             # LayerNorm 2 folded in: S = rstd (x (gamma o M)^T - mu c1) + M beta
+                    assert all(folds), "fused attn2 sites of one width fold norm2 alike"
+                    grp["ln_d"].copy_((m * grp["beta"]).sum(dim=-1))
+                    m = m * grp["gamma"]
+                grp["mcat"].copy_(m)
+                if any(folds):             # c1 sums the ROUNDED rows, so that the mean term cancels exactly
+                    grp["ln_c1"].copy_(grp["mcat"].float().sum(dim=-1))
+                grp["vw"].copy_(v.reshape(ns, B, c, 384))
         self._a2_dirty, self._a2_lam = False, float(lam)
 
     def time_rows(self, t: torch.Tensor, out: torch.Tensor):

@@ -44,6 +44,7 @@ for s in $steps; do
     prof)    export TMPDIR=/tmp
              run prof 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
              find "$out/prof" -name "*kernel_stats*.csv" | head -1 | xargs -r -I{} sh -c 'head -40 "{}" > '"$out"'/kernel_stats_top.csv'
+             python scripts/trace_gaps.py "$out/prof" > "$out/trace_gaps.txt" 2>&1; tail -n 45 "$out/trace_gaps.txt"
              find "$out/prof" -name "*kernel_trace*.csv" -size +20M -delete 2>/dev/null ;;
     pmc)     export TMPDIR=/tmp
              run pmc 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline ;;

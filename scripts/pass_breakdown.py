@@ -34,13 +34,14 @@ with torch.no_grad():
     _, t_clip = timed(lambda: mod.image_encoder.get_hidden_states(pix.expand(4, -1, -1, -1)))
     loop = mod.ddim_loop(4, 64); plan, be = loop.u, loop.be
     _, t_kv = timed(lambda: plan.set_cond(cond, 0))
-    ts = torch.linspace(999, 0, steps=50, dtype=torch.long, device=dev)
+    _, t_a2 = timed(lambda: plan.prepare_attn2(3.0))          # (dirty after set_cond: the fold of the fused attn2 sites)
+    ts = torch.linspace(999, 0, steps=50, dtype=torch.long)
     _, t_prep = timed(lambda: loop.prepare(ts, mod.alphas_cumprod))
     be.copy_(plan.lat_in, lat.to(dev))
     _, t_loop = timed(lambda: loop.run(3.0, False, 1.0))
     _, t_loop_eager = timed(lambda: loop.run(3.0, False, 1.0, use_graph=False))
     z, t_all = timed(lambda: PIPE._ddim_sample_ip(mod, tgt, src, pix, 50, dev, steer_scale=3.0, latents=lat))
     _, t_dec = timed(lambda: PIPE._latents_to_images(mod, z))
-print(f"prepare_conditioning {t_cond:.1f} ms (of which CLIP tower {t_clip:.1f}) | cond K/V projection {t_kv:.1f} | "
+print(f"prepare_conditioning {t_cond:.1f} ms (of which CLIP tower {t_clip:.1f}) | cond K/V projection {t_kv:.1f} | attn2 fold {t_a2:.1f} | "
       f"step tables {t_prep:.1f} | 50 graph replays {t_loop:.1f} ({t_loop/50:.2f}/step; eager {t_loop_eager:.1f}) | "
       f"_ddim_sample_ip total {t_all:.1f} | decode {t_dec:.1f}")
