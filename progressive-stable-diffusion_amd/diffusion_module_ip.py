@@ -127,11 +127,18 @@ class _InnerUNet:
             raise ValueError(f"attention processors disagree on delta_scale: {sorted(vals)}")
         return vals.pop()
 
+    def __call__(self, sample, timestep, encoder_hidden_states=None, **_):
+        """``UNet2DConditionModel.forward`` as OrdinalUNet.forward uses it (src/models/unet/unet.py:140-144):
+        ``unet(sample, timestep, encoder_hidden_states=cond).sample``."""
+        eps = self._plan.forward(sample.float(), timestep, encoder_hidden_states, lam=self.delta_scale())
+        return SimpleNamespace(sample=eps)
+
 
 class OrdinalUNet:
     """src/models/unet/unet.py:52-146: argument normalisation + sanity checks, then the engine."""
 
     def __init__(self, plan: UNetPlan, routing: bool, conditioning_dim=768, in_channels=4, out_channels=4):
+        self.compiled_handle = None
         self.unet = _InnerUNet(plan, routing)
         c = self.unet.config
         if c.in_channels != in_channels:
@@ -143,6 +150,21 @@ class OrdinalUNet:
                              f"vs {conditioning_dim} (config).")
         self._plan = plan
         self._cond_ref, self._cond_ver, self._cond_gen = None, -1, -1
+
+    # ``module.unet.unet = torch.compile(module.unet.unet, mode="reduce-overhead")`` (the reference's --compile switch,
+    # src/pipelines/inference/inference_pipeline_ip_data_augment.py:398-400): the assignment is accepted and the wrapper kept
+    # (``compiled_handle``), but the step keeps running on the engine - its captured hipGraph IS the launch-overhead removal
+    # that switch asks for, and there is nothing for a tracing compiler to trace.
+    @property
+    def unet(self):
+        return self._inner
+
+    @unet.setter
+    def unet(self, value):
+        if isinstance(value, _InnerUNet):
+            self._inner = value
+        else:
+            self.compiled_handle = value
 
     def parameters(self) -> Iterator[torch.Tensor]:
         return iter(self._plan.keep)

@@ -290,6 +290,33 @@ def _oracle_cfg(mod):
                         use_feature_purifier=dc.use_feature_purifier)
 
 
+def test_module_casts_and_compile_assignment_keep_the_engine_path(full_sd):
+    """The reference's augmentation pipeline does ``module = module.to(device); module = module.half(); module.eval()``
+    and, with --compile, ``module.unet.unet = torch.compile(module.unet.unet, mode="reduce-overhead")``
+    (src/pipelines/inference/inference_pipeline_ip_data_augment.py:372-379,398-400).  Here the casts return the module
+    itself (operand precision is the engine's: fp16 tiles, fp32 accumulation), a cast to another device type is refused,
+    the compile assignment is accepted without replacing the engine handle, and eps is bit-identical before and after."""
+    cfg = default_config(**{"dataset.image_size": 64})
+    mod = _module(cfg, full_sd)
+    lat = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(7))
+    t = torch.tensor([500, 20])
+    cond = torch.randn(2, 48, 768, generator=torch.Generator().manual_seed(8)) * 0.5
+    with torch.no_grad():
+        e0 = mod(lat, t, cond).clone()
+    assert mod.to(torch.device("cpu")) is mod and mod.to(torch.float16) is mod and mod.half() is mod and mod.float() is mod
+    assert mod.eval() is mod and mod.training is False
+    with pytest.raises(RuntimeError):
+        mod.to("cuda" if mod.device.type == "cpu" else "cpu")
+    inner = mod.unet.unet
+    mod.unet.unet = torch.compile(mod.unet.unet, mode="reduce-overhead")       # lazy: nothing is traced by the assignment
+    assert mod.unet.unet is inner and mod.unet.compiled_handle is not None
+    assert len(dict(mod.unet.unet.named_modules())) == 16                     # the processors stay reachable (delta_scale)
+    with torch.no_grad():
+        e1 = mod(lat, t, cond)
+        e2 = inner(lat, t, encoder_hidden_states=cond).sample                 # the diffusers-style call of unet.py:140-144
+    assert torch.equal(e0, e1) and torch.equal(e0, e2)
+
+
 @pytest.mark.parametrize("gates_on", [True, False])
 def test_sampler_matches_oracle_config1_shape(gates_on, full_sd):
     """BASELINE config 1 in miniature (64x64 image, 4 DDIM steps): variant (i) gates on with
