@@ -308,21 +308,25 @@ __global__ __launch_bounds__(NW * 64, DR <= 96 ? 2 : 1) void flash_kernel(const 
       const float t4 = vmax3(sacc[3][f][0], sacc[3][f][1], sacc[3][f][2]);
       mc[f] = vmax2(vmax3(t0, t1, t2), vmax3(t3, t4, sacc[3][f][3]));
     }
+    // A column is spread over four lanes (16 keys each), but whether ANY exponent of the wave exceeds 8 needs no cross-lane
+    // maximum: the lane-local maxima decide the (rare) branch, and only inside it are the columns' maxima united
+    // (v_permlane16/32_swap cost 18 ticks each with their hazard nops, scripts/micro/inst_cost.hip: eight per tile before).
+    float hot = mc[0];
 #pragma unroll
-    for (int f = 0; f < QF; ++f) {   // the maximum over the four lanes that share a query column: permlane swaps (VALU)
-      float ua, ub;
-      dadd_pair16(mc[f], ua, ub);
-      mc[f] = vmax2(ua, ub);
-    }
-    bool need = kt == 0;
+    for (int f = 1; f < QF; ++f) hot = vmax2(hot, mc[f]);
+    if (__any(kt == 0 || hot > 8.0f)) {                            // wave-uniform branch
 #pragma unroll
-    for (int f = 0; f < QF; ++f) {
-      float ua, ub;
-      dadd_pair32(mc[f], ua, ub);
-      mc[f] = vmax2(ua, ub);
-      need = need || (mc[f] > 8.0f);
-    }
-    if (__any(need)) {                                             // wave-uniform branch
+      for (int f = 0; f < QF; ++f) {   // the maximum over the four lanes that share a query column: permlane swaps (VALU)
+        float ua, ub;
+        dadd_pair16(mc[f], ua, ub);
+        mc[f] = vmax2(ua, ub);
+      }
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        float ua, ub;
+        dadd_pair32(mc[f], ua, ub);
+        mc[f] = vmax2(ua, ub);
+      }
 #pragma unroll
       for (int f = 0; f < QF; ++f) {
         const float dlt = (kt == 0 || mc[f] > 8.0f) ? mc[f] : 0.f;    // this column's reference moves by dlt (0: it stays)
