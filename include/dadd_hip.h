@@ -304,6 +304,15 @@ int dadd_aoe_interp_f32(const float* labels, const float* base, const float* del
 int dadd_purifier_tail_f16(const void* img, const void* dis, const void* gate, const float* gamma,
                            const float* beta, float* out, int M, int C, float eps, void* stream);
 
+/* Weight prefetch on a side branch: dadd_prefetch reads `bytes` at `ptr` on an internal stream that forks from `stream`
+ * at the call (inside a stream capture: a parallel branch of the graph, beside the kernels that precede the consumer), so
+ * that a later kernel finds the weights in the Infinity Cache instead of in HBM; dadd_prefetch_join makes `stream` wait for
+ * the branch - call it before dadd_graph_end and before anything that must not overlap.  No reference counterpart: the
+ * reference leaves weight residency to the cache hierarchy (nn.Module parameters behind OrdinalUNet.forward,
+ * src/models/unet/unet.py:140-144). */
+int dadd_prefetch(const void* ptr, int64_t bytes, void* stream);
+int dadd_prefetch_join(void* stream);
+
 /* ---- hipGraph capture of the step loop ----------------------------------------------------- */
 int dadd_graph_begin(void* stream);
 int dadd_graph_end(void* stream, void** graph_exec_out);

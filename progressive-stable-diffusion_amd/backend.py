@@ -37,6 +37,7 @@ class HipBackend:
         self.stream = torch.cuda.Stream(device=self.device)
         self._desc = L.IgemmDesc()
         self._capturing = False     # between graph_begin() and graph_end(): no cross-stream waits may be recorded
+        self._prof_on = False
         with torch.cuda.device(self.device):
             L.check(self.lib.dadd_init())
 
@@ -342,6 +343,16 @@ class HipBackend:
         L.check(self.lib.dadd_ddim_update_f32(_p(x), _p(eps_c), _p(eps_u), float(guidance), _p(guidance_dev),
                                               _p(coef), x.numel(), self.s))
 
+    def prefetch(self, t: torch.Tensor):
+        """Read ``t`` on the library's side stream (a parallel branch inside a graph capture): its lines are in the
+        Infinity Cache when a later kernel streams them.  ``prefetch_join`` before the capture ends."""
+        if self._prof_on:            # per-launch timing runs one kernel at a time: no side branch
+            return
+        L.check(self.lib.dadd_prefetch(_p(t), t.numel() * t.element_size(), self.s))
+
+    def prefetch_join(self):
+        L.check(self.lib.dadd_prefetch_join(self.s))
+
     # ------------------------------------------------------------------ graphs / profiling
     def graph_begin(self):
         L.check(self.lib.dadd_graph_begin(self.s))
@@ -362,11 +373,13 @@ class HipBackend:
     def prof_begin(self):
         """Start recording every kernel launch of the library (eager launches only)."""
         L.check(self.lib.dadd_prof_begin())
+        self._prof_on = True
 
     def prof_end(self):
         """-> list of (kernel name, microseconds, algorithmic flop, algorithmic bytes) in issue order; the time
         is the dispatch's own begin/end timestamp pair (what rocprofv3's kernel trace reports)."""
         n = C.c_int(0)
+        self._prof_on = False
         L.check(self.lib.dadd_prof_end(C.byref(n)))
         out, name, vals = [], C.c_char_p(), (C.c_double * 3)()
         for i in range(n.value):

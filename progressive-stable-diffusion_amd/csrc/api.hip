@@ -79,6 +79,68 @@ int dadd_device_info(int device, int64_t out[4]) {
   return DADD_OK;
 }
 
+// ---- weight prefetch on a side branch ------------------------------------------------------------------------------------
+// Every layer's weights are cold when its kernel starts (1.76 GB of UNet weights per step against 256 MB of Infinity
+// Cache): 3-8 us of a GEMM launch are the first misses of its weight stream (profiles/r03_zg_cold_hot_weights.txt).
+// dadd_prefetch() reads a weight tensor on a SIDE stream that forks from `stream` at the call (event) - inside a stream
+// capture that is a parallel branch of the graph, running beside the kernels that precede the consumer - and
+// dadd_prefetch_join() makes `stream` wait for the branch (before the capture ends / the results are used).  The reads
+// leave the lines in the memory-side Infinity Cache, which every XCD hits.
+namespace {
+hipStream_t g_pf_stream = nullptr;
+constexpr int PF_EVENTS = 64;
+hipEvent_t g_pf_ev[PF_EVENTS];
+int g_pf_next = 0;
+bool g_pf_open = false;
+
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9e3779b9u && sink != nullptr) *sink = acc;      // (never both: keeps the loads alive)
+}
+
+int pf_init() {
+  if (g_pf_stream != nullptr) return DADD_OK;
+  DADD_HIP(hipStreamCreateWithFlags(&g_pf_stream, hipStreamNonBlocking));
+  for (int i = 0; i < PF_EVENTS; ++i) DADD_HIP(hipEventCreateWithFlags(&g_pf_ev[i], hipEventDisableTiming));
+  return DADD_OK;
+}
+}  // namespace
+
+int dadd_prefetch(const void* ptr, int64_t bytes, void* stream) {
+  DADD_REQUIRE(ptr != nullptr && bytes >= 0 && dadd_aligned16(ptr), "prefetch: null / unaligned pointer");
+  if (bytes < 16) return DADD_OK;
+  int rc = pf_init();
+  if (rc != DADD_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t e = g_pf_ev[g_pf_next];
+  g_pf_next = (g_pf_next + 1) % PF_EVENTS;
+  DADD_HIP(hipEventRecord(e, s));                       // fork: the branch starts when `stream` reaches this point
+  DADD_HIP(hipStreamWaitEvent(g_pf_stream, e, 0));
+  const size_t n16 = (size_t)bytes / 16;
+  int blocks = (int)((n16 + 256 * 16 - 1) / (256 * 16));    // >= 16 loads per thread, at most 48 workgroups
+  if (blocks > 48) blocks = 48;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, g_pf_stream, static_cast<const uint4*>(ptr), n16,
+                     static_cast<unsigned*>(nullptr));
+  DADD_LAUNCH_CHECK();
+  g_pf_open = true;
+  return DADD_OK;
+}
+
+int dadd_prefetch_join(void* stream) {
+  if (!g_pf_open) return DADD_OK;
+  hipEvent_t e = g_pf_ev[g_pf_next];
+  g_pf_next = (g_pf_next + 1) % PF_EVENTS;
+  DADD_HIP(hipEventRecord(e, g_pf_stream));
+  DADD_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), e, 0));
+  g_pf_open = false;
+  return DADD_OK;
+}
+
 int dadd_graph_begin(void* stream) {
   DADD_REQUIRE(g_dadd_prof_on == 0, "graph_begin: profiling is active");
   DADD_HIP(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));

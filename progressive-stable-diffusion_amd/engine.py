@@ -153,6 +153,14 @@ HALO_DUO = False
 # (DADD_EPI_GNAPPLY, csrc/igemm.hip splitk_finish_gnapply_kernel): one launch instead of finish + single-launch GroupNorm
 FINISH_GN_APPLY = True
 
+# Weight prefetch on a side branch of the graph (csrc/api.hip dadd_prefetch): how many weight-bearing launches ahead of
+# its consumer a weight tensor is read into the Infinity Cache (0 = off), and the smallest tensor worth a branch.
+# MEASURED AND OFF (profiles/r03_zh_weight_prefetch_ab.txt, same box, A B A B): 385.7 / 385.0 ms per pass without, 535.4 /
+# 534.8 ms with - a captured graph with ~80 side branches per step makes hipGraphLaunch host-bound (host queue time 277 ->
+# 504 ms per pass), far more than the 3-8 us per launch that hot weights save (profiles/r03_zg_cold_hot_weights.txt).
+WEIGHT_PREFETCH_AHEAD = int(os.environ.get("DADD_WEIGHT_PREFETCH", "0"))
+WEIGHT_PREFETCH_MIN_BYTES = 2 * 1024 * 1024
+
 # GroupNorm statistics written by the producing GEMM's epilogue (no gn_stats launch, one read of the tensor less).
 GN_FROM_EPILOGUE = True
 GN_FUSED_MAX_BYTES = 16 * 1024       # csrc/norm.hip: below this slab size the single-launch LDS GroupNorm runs
@@ -864,6 +872,31 @@ class UNetPlan(_Plan):
         self.rec(self._emit_eps, g, self.w("conv_out.weight", pack_conv_cout4), self.f("conv_out.bias"))
         self.pool.put(h, g)
         assert not self.gn_ready, "a GroupNorm written by a finish kernel was never consumed"
+        self._insert_weight_prefetch()
+
+    def _insert_weight_prefetch(self):
+        """Every layer's weights are cold when its kernel starts (1.76 GB per step against 256 MB of Infinity Cache).  A
+        launch whose weights are at least WEIGHT_PREFETCH_MIN_BYTES gets a ``be.prefetch`` of them WEIGHT_PREFETCH_AHEAD
+        weight-bearing launches earlier - a side branch of the captured graph (``dadd_prefetch``) - and the plan ends with
+        the join.  Reads only: results are unchanged."""
+        if not WEIGHT_PREFETCH_AHEAD:
+            return
+        wops = []                       # (op index, weight tensor) of the launches that stream a weight operand
+        for i, (fn, a, k) in enumerate(self.ops):
+            name = getattr(fn, "__name__", "")
+            if name == "igemm":
+                wops.append((i, a[1]))
+            elif name in ("ffn_block", "tf_head"):
+                wops.append((i, a[1]))
+        inserts = []
+        for j, (i, w) in enumerate(wops):
+            if w.numel() * w.element_size() < WEIGHT_PREFETCH_MIN_BYTES or j < WEIGHT_PREFETCH_AHEAD:
+                continue
+            inserts.append((wops[j - WEIGHT_PREFETCH_AHEAD][0], w))
+        for at, w in sorted(inserts, key=lambda t: -t[0]):       # back to front: earlier indices stay valid
+            self.ops.insert(at, (self.be.prefetch, (w,), {}))
+        if inserts:
+            self.ops.append((self.be.prefetch_join, (), {}))
 
     # -- step-invariant preparation ----------------------------------------------------------------
     def set_cond(self, cond: torch.Tensor, slot: int = 0):

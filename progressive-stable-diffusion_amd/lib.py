@@ -78,6 +78,8 @@ PROTOTYPES = {
     "dadd_purifier_tail_f16": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, f32, vp]),
     "dadd_begin_step": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "dadd_ddim_update_f32": (C.c_int, [vp, vp, vp, f32, vp, vp, i64, vp]),
+    "dadd_prefetch": (C.c_int, [vp, i64, vp]),
+    "dadd_prefetch_join": (C.c_int, [vp]),
     "dadd_graph_begin": (C.c_int, [vp]),
     "dadd_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "dadd_graph_launch": (C.c_int, [vp, vp]),

@@ -199,6 +199,12 @@ class TorchRefBackend:
             g_out, gam, bet, eps_o = gn_apply
             self.groupnorm(out, None, gam, bet, g_out, None, 32, eps_o, gn_apply_silu)
 
+    def prefetch(self, t):
+        pass
+
+    def prefetch_join(self):
+        pass
+
     def groupnorm(self, x1, x2, gamma, beta, out, ws, groups, eps, silu, ws_chunks=0):
         x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
         if ws_chunks:                   # statistics come from the producer's partials, not from x
