@@ -808,6 +808,34 @@ def test_begin_step_and_graph_replay(hip):
     hip.graph_destroy(g)
 
 
+def test_weight_prefetch_branch(hip):
+    """dadd_prefetch / dadd_prefetch_join: a read-only side branch (eager: a second stream; captured: a parallel branch of
+    the graph).  Results of the kernels around it are unchanged, the graph replays, and a join without an open branch is
+    a no-op.  (Off in the shipped plans: profiles/r03_zh_weight_prefetch_ab.txt.)"""
+    x, w, w2 = rnd((2, 16, 16, 640), 130), rnd((640, 640), 131, 0.04), rnd((1280, 9 * 1280), 132, 0.01)
+    xd, wd, w2d = dev(hip, x), dev(hip, w), dev(hip, w2)
+    o_ref, o1, o2 = (hip.zeros((2, 16, 16, 640), F16) for _ in range(3))
+    hip.igemm(xd, wd, o_ref)
+    hip.prefetch_join()                      # nothing open
+    hip.prefetch(w2d)                        # 29.5 MB: 48 workgroups
+    hip.prefetch(wd[:1, :8])                 # 16 bytes: one load
+    hip.igemm(xd, wd, o1)
+    hip.prefetch_join()
+    hip.synchronize()
+    assert torch.equal(o1.cpu(), o_ref.cpu())
+    hip.graph_begin()
+    hip.prefetch(w2d)
+    hip.igemm(xd, wd, o2)
+    hip.prefetch_join()
+    g = hip.graph_end()
+    for _ in range(3):
+        hip.zero_(o2)
+        hip.graph_launch(g)
+        hip.synchronize()
+        assert torch.equal(o2.cpu(), o_ref.cpu())
+    hip.graph_destroy(g)
+
+
 def test_profiling_hooks(hip):
     """Every launch between prof_begin / prof_end is recorded with its kernel name, its own begin/end
     timestamps and its algorithmic flop / bytes; capture is refused while profiling."""
