@@ -661,10 +661,8 @@ int dadd_init_attention() {
   if (rc == DADD_OK) rc = flash_attr<64, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<96, 1, true>();
   if (rc == DADD_OK) rc = flash_attr<80, 2, true>();
-  if (rc == DADD_OK) rc = flash_attr<80, 1, true>();
   if (rc == DADD_OK) rc = flash_attr<160, 2, true>();
   if (rc == DADD_OK) rc = flash_attr<160, 1, true>();
-  if (rc == DADD_OK) rc = flash_attr<160, 1, true, 2>();
   if (rc == DADD_OK) rc = flash_attr<512, 1, false>();
   return rc;
 }
@@ -705,15 +703,11 @@ extern "C" int dadd_attn_f16(const void* q, const void* k, const void* v, void* 
       return launch_flash<40, 2, true>(a, s);
     }
     case 64: return launch_flash<64, 2, true>(a, s);     // CLIP ViT towers (257 tokens, 16 x 64)
-    case 80: {
-      static const int var = getenv("DADD_FLASH80") ? atoi(getenv("DADD_FLASH80")) : 0;
-      return var == 1 ? launch_flash<80, 1, true>(a, s) : launch_flash<80, 2, true>(a, s);
-    }
+    case 80: return launch_flash<80, 2, true>(a, s);     // (16 queries per wave measured slower at 32x32, B = 4: 29.7 against 27.2 us)
     case 96: return launch_flash<96, 1, true>(a, s);     // nn.MultiheadAttention(768, 8) of the resampler / purifier
-    case 160: {
-      static const int var = getenv("DADD_FLASH160") ? atoi(getenv("DADD_FLASH160")) : 0;
-      return var == 1 ? launch_flash<160, 1, true>(a, s) : var == 2 ? launch_flash<160, 1, true, 2>(a, s) : launch_flash<160, 2, true>(a, s);
-    }
+    case 160:   // 16 queries per wave while 32 would leave most of the chip idle (16x16 maps at B = 4: 64 -> 128 workgroups,
+                // 15.9 -> 10.7 us, profiles/r03_zi_flash_small.txt; two-wave workgroups measured 12.8)
+      return ((long)B * heads * ((Nq + 127) / 128) < 256) ? launch_flash<160, 1, true>(a, s) : launch_flash<160, 2, true>(a, s);
     case 512: return launch_flash<512, 1, false>(a, s);
     default:
       dadd_set_error("attn: unsupported head dim %d (40, 64, 80, 96, 160, 512)", d);
