@@ -459,6 +459,7 @@ struct XattnArgs {
   const float* lambda_dev;   // lambda read from device memory when non-null (one captured graph serves a lambda sweep)
   float lambda;
   int B, N, H, T, ldkv, C;
+  int qpb;           // queries per workgroup: 256 (four 16-query fragments per wave) or 64 (one) on the small maps
   float scale_log2;
 };
 
@@ -524,8 +525,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(const XattnArgs p) {
     }
 
   const size_t tok0 = (size_t)b * p.N;
-  const int q0 = blockIdx.x * 256;
-  for (int qfi = wave; qfi < 16; qfi += 4) {
+  const int q0 = blockIdx.x * p.qpb;
+  for (int qfi = wave; qfi < (p.qpb >> 4); qfi += 4) {
     const int qbase = q0 + qfi * 16;
     if (qbase >= p.N) break;  // wave-uniform
     int qrow = qbase + li;
@@ -636,8 +637,11 @@ int launch_flash(const FlashArgs& a, hipStream_t s) {
 }
 
 template <int DR>
-int launch_xattn(const XattnArgs& a, int mode, hipStream_t s) {
-  dim3 grid((a.N + 255) / 256, a.B * a.H);
+int launch_xattn(XattnArgs a, int mode, hipStream_t s) {
+  // 256 queries per workgroup leave the small maps on a fraction of the CUs (16x16 at B = 4: 32 workgroups); with 64 every
+  // wave handles one 16-query fragment and the grid is four times as large
+  a.qpb = ((long)a.B * a.H * ((a.N + 255) / 256) < 512) ? 64 : 256;
+  dim3 grid((a.N + a.qpb - 1) / a.qpb, a.B * a.H);
   static const std::string nm = "xattn_kernel<" + std::to_string(DR);
   static const std::string n2t = nm + ", 2, true>", n3f = nm + ", 3, false>", n2f = nm + ", 2, false>";
   const double tok = (double)a.B * a.N, c = (double)a.C;
