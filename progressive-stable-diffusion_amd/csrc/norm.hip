@@ -375,6 +375,7 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   p.rows_per_chunk = (HW + nchunk - 1) / nchunk;
   p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
   p.rows_per_block = 8 * p.RP;
+  if ((long)B * ((HW + p.rows_per_block - 1) / p.rows_per_block) < 256) p.rows_per_block = 4 * p.RP;   // small maps: fill the chip
   const int nrb = (HW + p.rows_per_block - 1) / p.rows_per_block;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (ws_chunks > 0) {     // partials already written by the producer's epilogue: [B][ws_chunks][groups][2] at ws
