@@ -369,6 +369,7 @@ extern "C" int dadd_groupnorm_f16(const void* x1, int C1, const void* x2, int C2
   // stat chunks: at least two passes of rows per block, at most GN_CHUNK_MAX per sample (few enough that every
   // apply block combines them itself: no finalize launch)
   int nchunk = HW / (2 * p.RP > 16 ? 2 * p.RP : 16);
+  if ((long)B * nchunk < 256) nchunk = HW / (4 * p.RP);      // small maps: one four-row trip per workgroup fills more of the chip
   if (nchunk > GN_CHUNK_MAX) nchunk = GN_CHUNK_MAX;
   if (nchunk < 1) nchunk = 1;
   p.stats = ws + (size_t)B * (DADD_GN_MAX_CHUNKS - 1) * groups * 2;   // last chunk slot of the workspace
