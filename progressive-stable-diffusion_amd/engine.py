@@ -245,9 +245,10 @@ def choose_splitk(m: int, n: int, k: int, tile_n: int) -> int:
 # choose_tiling().  TILING_OVERRIDE (same keys) is the sweep's own hook and wins over both.
 TILING_OVERRIDE: Dict[Tuple, Tuple[int, int, int, int]] = {}
 try:
-    from .tiling_table import TABLE as TILING_TABLE
+    from .tiling_table import TABLE as TILING_TABLE, TABLE_R3 as TILING_TABLE_R3
 except ImportError:          # no table committed yet
-    TILING_TABLE = {}
+    TILING_TABLE, TILING_TABLE_R3 = {}, {}
+TILING_R3 = True             # the round-3 entries of the table (64-row tiles with K slices on the small maps)
 
 
 def tiling_key(m, n, k, taps, geglu, residual, ups=0, stride=1):
@@ -257,7 +258,7 @@ def tiling_key(m, n, k, taps, geglu, residual, ups=0, stride=1):
 def plan_tiling(m, n, k, taps, geglu, residual, ups=0, stride=1) -> Tuple[int, int, int, int]:
     """(tile_m, tile_n, splitk, tune) of one implicit GEMM."""
     key = tiling_key(m, n, k, taps, geglu, residual, ups, stride)
-    hit = TILING_OVERRIDE.get(key) or TILING_TABLE.get(key)
+    hit = TILING_OVERRIDE.get(key) or (TILING_TABLE_R3.get(key) if TILING_R3 else None) or TILING_TABLE.get(key)
     if hit is not None:
         return tuple(hit)
     tile_n = 128 if geglu or n % 160 else 160

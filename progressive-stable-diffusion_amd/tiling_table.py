@@ -23,3 +23,19 @@ TABLE = {
     (16384, 320, 1280, 1, False, True, 0, 1): (128, 160, 1, 0),
     (16384, 2560, 320, 1, True, False, 0, 1): (128, 128, 1, 32),
 }
+
+# Round 3; these win over TABLE when engine.TILING_R3 is set (the A/B switch of the same-box comparison):
+TABLE_R3 = {
+    # round 3 (gpurun_out/r4t -> profiles/r03_zl_tile_sweep.txt): the sweep also tries 64-row tiles WITH K slices on the
+    # 16x16 / 8x8 maps (two workgroups per CU keep twice the bytes in flight) - the finish kernels got cheaper this round.
+    # Not taken: (1024, 1280, 1280, residual) -> (64, 160, 2, 0), 2 us per launch for 15 more finish launches per step
+    (1024, 1280, 1920, 1, False, False, 0, 1): (64, 160, 2, 0),
+    (1024, 1280, 11520, 9, False, True, 0, 1): (128, 160, 4, 0),
+    (256, 1280, 11520, 9, False, True, 0, 1): (64, 160, 8, 0),
+    (256, 1280, 11520, 9, False, False, 0, 1): (64, 160, 8, 0),
+    (256, 1280, 5120, 1, False, True, 0, 1): (64, 160, 8, 0),
+    (4096, 640, 2880, 9, False, False, 0, 1): (128, 160, 2, 0),
+    (256, 1280, 2560, 1, False, False, 0, 1): (64, 64, 4, 0),
+    (4096, 640, 1920, 1, False, False, 0, 1): (128, 160, 2, 0),
+    (4096, 640, 2560, 1, False, True, 0, 1): (128, 160, 2, 0),
+}

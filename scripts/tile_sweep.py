@@ -42,10 +42,14 @@ def candidates(key, N_CU=256):
                 out.append((64, tn, 1, L.TUNE_NODMA | L.TUNE_SHALLOW))
         out.append((128, tn, 1, L.TUNE_NODMA))
     if not geglu and not ups and n % 64 == 0:
-        for sk in (1, 2, 4):
-            if sk > 1 and nkt // sk < 8:
+        for sk in (1, 2, 4, 8, 16):
+            if sk > 1 and (nkt // sk < 8 or math.ceil(m / 64) * (n // 64) * sk > 8 * N_CU):
                 continue
             out.append((64, 64, sk, 0))
+        if n % 160 == 0 and m <= 1024:       # the 16x16 / 8x8 maps: 64-row tiles with K slices (two workgroups per CU)
+            for sk in (2, 4, 8):
+                if nkt // sk >= 8 and math.ceil(m / 64) * (n // 160) * sk <= 4 * N_CU:
+                    out.append((64, 160, sk, 0))
         if n % 128 == 0 and n % 160:
             out.append((64, 128, 1, 0))
     return out
@@ -115,6 +119,7 @@ def main():
     E.TILING_OVERRIDE.clear()
     saved_table = dict(E.TILING_TABLE)
     E.TILING_TABLE.clear()                       # sweep from the rules, not from a previous table
+    E.TILING_TABLE_R3.clear()
     base, counts, base_total = measure()
     keys = list(base)
     cands = {k: candidates(k) for k in keys}
