@@ -30,8 +30,11 @@ constexpr int B2_BYTES = BN2 * BK * 2;        // 20 KB
 template <int BM> constexpr int a_bytes() { return BM * BK * 2; }
 template <int BM> constexpr int stage1() { return a_bytes<BM>() + B1_BYTES; }
 template <int BM> constexpr int p_bytes() { return BM * P_STRIDE; }
+// VW ring of phase 2: four stages (three tiles in flight) where they fit beside P (BM = 64: 56 + 80 KB), else two.  With two
+// stages every one of the twelve 20 KB tiles paid its whole L2 -> LDS latency (one tile in flight under 20 MFMAs per wave).
+template <int BM> constexpr int nst2() { return p_bytes<BM>() + 4 * B2_BYTES <= 160 * 1024 - 1024 ? 4 : 2; }
 template <int BM> constexpr int smem_bytes() {
-  return (p_bytes<BM>() + 2 * B2_BYTES) > 2 * stage1<BM>() ? (p_bytes<BM>() + 2 * B2_BYTES) : 2 * stage1<BM>();
+  return (p_bytes<BM>() + nst2<BM>() * B2_BYTES) > 2 * stage1<BM>() ? (p_bytes<BM>() + nst2<BM>() * B2_BYTES) : 2 * stage1<BM>();
 }
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -194,7 +197,12 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
     for (int j = 0; j < 5; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lptr_t)(sa + j * 4096), 16, vv[j], so, 0, 0);
   };
+  constexpr int NST2 = nst2<BM>();
   issue2(0, 0);
+  if constexpr (NST2 == 4) {
+    if (1 < n_it2) issue2(1, 1);
+    if (2 < n_it2) issue2(2, 2);
+  }
 
   // ---------------------------------------------------------------- softmax per 16-column group, P -> LDS (fp16)
 #pragma unroll
@@ -234,10 +242,17 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc2[j][i] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NST2 == 4) {      // tiles it + 1 and it + 2 (five DMA instructions each, issued after tile `it`) may stay in flight
+      const int younger = min(2, n_it2 - 1 - it);
+      if (younger == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();                                   // VW tile `it` landed (first time: P writes visible too)
-    if (it + 1 < n_it2) issue2(it + 1, (it + 1) & 1);
-    const char* vt = smem + P_BYTES + (it & 1) * B2_BYTES;
+    if (it + NST2 - 1 < n_it2) issue2(it + NST2 - 1, (it + NST2 - 1) & (NST2 - 1));
+    const char* vt = smem + P_BYTES + (it & (NST2 - 1)) * B2_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       h8 pa[MI], wb[5];
@@ -253,6 +268,19 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
           acc2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], pa[i], acc2[j][i], 0, 0, 0);
     }
     if (kt == nk2 - 1) {                               // epilogue of column tile nt
+      // All bias / residual loads of the tile first, then the arithmetic and the stores: written load - use - store per
+      // (i, j) the compiler kept that order (the stores may alias the next loads) and the wave paid 2 x 5 x MI dependent
+      // round trips behind s_waitcnt vmcnt(0) - about half of this kernel's time.
+      f4 bias4[5];
+      h4 res4[5][MI];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int n = nt * BN2 + wn * 80 + j * 16 + g * 4;
+        bias4[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          res4[j][i] = *reinterpret_cast<const h4*>(p.residual + ((size_t)m0 + wm * WMR + i * 16 + mc) * C + n);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const size_t m = (size_t)m0 + wm * WMR + i * 16 + mc;
@@ -260,9 +288,8 @@ __global__ __launch_bounds__(256, 1) void attn2_fused_kernel(const Attn2Args p) 
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const int n = nt * BN2 + wn * 80 + j * 16 + g * 4;
-          f4 v = acc2[j][i];
-          if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + n);
-          const h4 rv = *reinterpret_cast<const h4*>(p.residual + m * C + n);
+          const f4 v = acc2[j][i] + bias4[j];
+          const h4 rv = res4[j][i];
           const h4 o = {(half_t)(v[0] + (float)rv[0]), (half_t)(v[1] + (float)rv[1]),
                         (half_t)(v[2] + (float)rv[2]), (half_t)(v[3] + (float)rv[3])};
           *reinterpret_cast<h4*>(p.out + m * C + n) = o;
