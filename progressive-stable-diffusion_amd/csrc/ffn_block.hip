@@ -387,17 +387,31 @@ __global__ __launch_bounds__(512, 2) void ffn_block_kernel(const FfnArgs p) {
   // ---- out = proj_out + bias + outer residual; GroupNorm partials of the ROUNDED values, one chunk per 32 rows
   float* scratch = reinterpret_cast<float*>(xbuf + 16384) + wave * 320;     // [160 columns][2] per wave; h4 is dead
   const int bsmp = m0 / p.HW;
+  // all residual / bias operands first (the fragments of X are dead: registers are free), then arithmetic and stores:
+  // written load - use - store per (column block, row fragment) the wave paid twenty dependent round trips
+  h4 resv[2][5][2];
+  f4 biasv[2][5];
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
     for (int tl = 0; tl < 5; ++tl) {
       const int n = nh * 160 + wn * 80 + tl * 16 + g * 4;
-      const f4 bias = *reinterpret_cast<const f4*>(p.bp + n);
+      biasv[nh][tl] = *reinterpret_cast<const f4*>(p.bp + n);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        resv[nh][tl][i] = *reinterpret_cast<const h4*>(p.xres + (size_t)(m0 + xrow + i * 16) * C + n);
+    }
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int tl = 0; tl < 5; ++tl) {
+      const int n = nh * 160 + wn * 80 + tl * 16 + g * 4;
+      const f4 bias = biasv[nh][tl];
       float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const size_t m = (size_t)(m0 + xrow + i * 16);
-        const h4 rv = *reinterpret_cast<const h4*>(p.xres + m * C + n);
+        const h4 rv = resv[nh][tl][i];
         const f4 v = acc2[nh][tl][i] + bias;
         h4 o;
 #pragma unroll
